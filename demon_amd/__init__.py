@@ -1,0 +1,9 @@
+"""demon_amd -- MI355X-native (gfx950) DeMoN inference path behind the reference's Python API.
+
+The numeric work lives in libdemon_hip.so (demon_amd/csrc, C ABI in include/demon_hip.h); this package is
+the thin host side: ctypes binding, weight table / IO, and mirrors of the reference interfaces
+`depthmotionnet.networks_original` and `lmbspecialops`.
+"""
+from .engine import DemonContext, DemonError  # noqa: F401
+from .runtime import get_context, set_default_weights, default_weights  # noqa: F401
+from . import weights  # noqa: F401

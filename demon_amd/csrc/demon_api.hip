@@ -1,0 +1,1039 @@
+// demon_api.hip -- context, weight packing, network topology and the C ABI of libdemon_hip.so.
+//
+// The three reference networks (python/depthmotionnet/networks_original.py:22-255) are built here as
+// fixed kernel sequences over one device arena: weights are repacked once for the MFMA kernels, every
+// activation lives at a fixed address, layer outputs are written straight into the channel slices of
+// their concat buffers, and each sequence is captured into a hipGraph.  Nothing is allocated and no
+// host round trip happens between the stages of examples/example.py:87-99.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/demon_hip.h"
+#include "internal.h"
+
+using namespace demon;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Layer {
+    std::string name;  // "<scope>/<layer>"
+    enum Kind { CONV, DECONV, DENSE } kind = CONV;
+    int Cin = 0, Cout = 0, kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0, act = 0;
+    View in, out;
+    const float *scale = nullptr;
+    int K = 0, Kpad = 0, Mpad = 0, ncls = 1;
+    float *d_wp = nullptr, *d_bias = nullptr;
+    KEntry *d_ktab = nullptr;
+    bool have_kernel = false, have_bias = false;
+    std::vector<int64_t> kernel_dims;  // TF layout
+};
+
+struct Step {
+    std::string name;
+    std::string kernel;
+    double flops_per_sample = 0, bytes_per_sample = 0, bytes_fixed = 0;
+    std::function<void(int n, hipStream_t s)> fn;
+};
+
+struct Variable {
+    std::string name;
+    Layer *layer;
+    bool is_bias;
+    int64_t dims[4];
+    int ndim;
+    int64_t count;
+};
+
+}  // namespace
+
+struct demon_ctx {
+    int device = 0, max_batch = 0, H = 0, W = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocations;
+    std::map<std::string, View> buffers;
+    std::vector<std::unique_ptr<Layer>> layers;
+    std::vector<Variable> variables;
+    std::map<std::string, int> var_index;
+    std::vector<Step> net_boot, net_iter, net_refine;
+    int opt_hipgraph = 1, opt_f2d_method = 0;
+    std::map<std::string, hipGraphExec_t> graphs;
+    // io / state
+    View image_pair, image2_2, flowconf5, flowconf2, depth2, normal2, depth0;
+    float *d_rot = nullptr, *d_trans = nullptr, *d_scale = nullptr, *d_motion = nullptr, *d_intrinsics = nullptr;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                             \
+            return DEMON_ERR_HIP;                                                                       \
+        }                                                                                               \
+    } while (0)
+
+int fail(demon_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+float *dev_alloc(demon_ctx *c, size_t bytes)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    c->allocations.push_back(p);
+    return (float *)p;
+}
+
+// named activation buffer, sized for max_batch; same name -> same memory (the five sub-nets run one
+// after the other on one stream and share their encoder/decoder buffers)
+View buffer(demon_ctx *c, const std::string &key, int C, int H, int W)
+{
+    auto it = c->buffers.find(key);
+    if (it != c->buffers.end()) return it->second;
+    View v;
+    v.base = dev_alloc(c, sizeof(float) * (size_t)c->max_batch * C * H * W);
+    v.Ctot = C; v.c0 = 0; v.C = C; v.H = H; v.W = W;
+    c->buffers[key] = v;
+    return v;
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+void add_variable(demon_ctx *c, Layer *L, bool is_bias)
+{
+    Variable v;
+    v.name = L->name + (is_bias ? "/bias" : "/kernel");
+    v.layer = L;
+    v.is_bias = is_bias;
+    v.ndim = 0;
+    v.count = 1;
+    if (is_bias) {
+        v.dims[v.ndim++] = L->Cout;
+    } else {
+        for (int64_t d : L->kernel_dims) v.dims[v.ndim++] = d;
+    }
+    for (int i = 0; i < v.ndim; ++i) v.count *= v.dims[i];
+    c->var_index[v.name] = (int)c->variables.size();
+    c->variables.push_back(v);
+}
+
+// ---- layer planning (geometry, K table) ------------------------------------------------------------
+bool plan_layer(demon_ctx *c, Layer *L)
+{
+    const int H = L->in.H, W = L->in.W;
+    std::vector<KEntry> tab;
+    if (L->kind == Layer::CONV) {
+        L->K = L->kh * L->kw * L->Cin;
+        L->ncls = 1;
+    } else if (L->kind == Layer::DECONV) {
+        L->K = 4 * L->Cin;
+        L->ncls = 4;
+    } else {
+        L->K = L->Cin;
+        L->ncls = 1;
+    }
+    L->Kpad = round_up(L->K, 16);
+    L->Mpad = round_up(L->Cout, 32);
+    tab.assign((size_t)L->ncls * L->Kpad, KEntry{0, (int)((unsigned)(-30000) << 16)});
+    auto pack = [](int dy, int dx) { return (int)(((unsigned)dy << 16) | ((unsigned)dx & 0xffffu)); };
+    if (L->kind == Layer::CONV) {
+        for (int a = 0; a < L->kh; ++a)
+            for (int b = 0; b < L->kw; ++b)
+                for (int ci = 0; ci < L->Cin; ++ci) {
+                    const int k = (a * L->kw + b) * L->Cin + ci;
+                    const int dy = a - L->ph, dx = b - L->pw;
+                    tab[k] = KEntry{ci * H * W + dy * W + dx, pack(dy, dx)};
+                }
+    } else if (L->kind == Layer::DECONV) {
+        // output (2y+py, 2x+px) of the cropped k4 s2 transposed conv reads input rows
+        //   py = 0: taps a = 1 (dy = 0), a = 3 (dy = -1);   py = 1: a = 0 (dy = +1), a = 2 (dy = 0)
+        static const int tap_d[2][2] = {{0, -1}, {1, 0}};
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            for (int ty = 0; ty < 2; ++ty)
+                for (int tx = 0; tx < 2; ++tx)
+                    for (int ci = 0; ci < L->Cin; ++ci) {
+                        const int k = (ty * 2 + tx) * L->Cin + ci;
+                        const int dy = tap_d[py][ty], dx = tap_d[px][tx];
+                        tab[(size_t)cls * L->Kpad + k] = KEntry{ci * H * W + dy * W + dx, pack(dy, dx)};
+                    }
+        }
+    } else {
+        for (int k = 0; k < L->K; ++k) tab[k] = KEntry{k, pack(0, 0)};
+    }
+    L->d_ktab = (KEntry *)dev_alloc(c, tab.size() * sizeof(KEntry));
+    L->d_wp = dev_alloc(c, sizeof(float) * (size_t)L->ncls * L->Kpad * L->Mpad);
+    L->d_bias = dev_alloc(c, sizeof(float) * L->Mpad);
+    if (!L->d_ktab || !L->d_wp || !L->d_bias) return false;
+    if (hipMemcpy(L->d_ktab, tab.data(), tab.size() * sizeof(KEntry), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (hipMemset(L->d_wp, 0, sizeof(float) * (size_t)L->ncls * L->Kpad * L->Mpad) != hipSuccess) return false;
+    if (hipMemset(L->d_bias, 0, sizeof(float) * L->Mpad) != hipSuccess) return false;
+    return true;
+}
+
+// TF layout -> packed [cls][Kpad][Mpad] (host side, then one upload)
+int upload_kernel(demon_ctx *c, Layer *L, const float *w)
+{
+    std::vector<float> wp((size_t)L->ncls * L->Kpad * L->Mpad, 0.0f);
+    if (L->kind == Layer::CONV || L->kind == Layer::DENSE) {
+        // HWIO [kh][kw][Cin][Cout] (dense: [in][out]) is already [k][co] with k = (a*kw+b)*Cin+ci
+        for (int k = 0; k < L->K; ++k) memcpy(&wp[(size_t)k * L->Mpad], w + (size_t)k * L->Cout, sizeof(float) * L->Cout);
+    } else {
+        static const int tap_a[2][2] = {{1, 3}, {0, 2}};
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            for (int ty = 0; ty < 2; ++ty)
+                for (int tx = 0; tx < 2; ++tx) {
+                    const int a = tap_a[py][ty], b = tap_a[px][tx];
+                    for (int ci = 0; ci < L->Cin; ++ci) {
+                        const int k = (ty * 2 + tx) * L->Cin + ci;
+                        float *dst = &wp[((size_t)cls * L->Kpad + k) * L->Mpad];
+                        for (int co = 0; co < L->Cout; ++co) dst[co] = w[(((size_t)a * 4 + b) * L->Cout + co) * L->Cin + ci];
+                    }
+                }
+        }
+    }
+    HIP_TRY(c, hipMemcpy(L->d_wp, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
+    L->have_kernel = true;
+    return DEMON_OK;
+}
+
+void run_layer(const Layer *L, int n, hipStream_t s)
+{
+    ConvArgs a;
+    a.in = L->in.ptr();
+    a.out = L->out.ptr();
+    a.wp = L->d_wp;
+    a.bias = L->d_bias;
+    a.ktab = L->d_ktab;
+    a.scale = L->scale;
+    a.N = n;
+    a.H = L->in.H;
+    a.W = L->in.W;
+    a.in_n_stride = L->in.n_stride();
+    a.Cout = L->Cout;
+    a.Mpad = L->Mpad;
+    a.Kpad = L->Kpad;
+    a.Ho = L->out.H;
+    a.Wo = L->out.W;
+    a.out_n_stride = L->out.n_stride();
+    a.act = L->act;
+    a.cls_w_stride = (long)L->Kpad * L->Mpad;
+    if (L->kind == Layer::DECONV) {
+        a.Hp = L->in.H; a.Wp = L->in.W; a.sy = 1; a.sx = 1; a.osy = 2; a.osx = 2;
+    } else {
+        a.Hp = L->out.H; a.Wp = L->out.W; a.sy = L->sh; a.sx = L->sw; a.osy = 1; a.osx = 1;
+    }
+    const long P = (long)n * a.Hp * a.Wp;
+    launch_conv_mfma(a, choose_conv_tile(L->Mpad, P, L->ncls), L->ncls, s);
+}
+
+// ---- topology builder ---------------------------------------------------------------------------------
+struct Builder {
+    demon_ctx *c;
+    std::vector<Step> *steps;
+    std::string scope;
+    bool ok = true;
+
+    Layer *make(const std::string &name, Layer::Kind kind, View in, View out, int kh, int kw, int sh, int sw, int act,
+                const float *scale = nullptr)
+    {
+        auto L = std::make_unique<Layer>();
+        L->name = scope + "/" + name;
+        L->kind = kind;
+        L->Cin = in.C; L->Cout = out.C;
+        L->kh = kh; L->kw = kw; L->sh = sh; L->sw = sw; L->ph = kh / 2; L->pw = kw / 2; L->act = act;
+        L->in = in; L->out = out; L->scale = scale;
+        if (kind == Layer::CONV) L->kernel_dims = {kh, kw, in.C, out.C};
+        else if (kind == Layer::DECONV) L->kernel_dims = {4, 4, out.C, in.C};
+        else L->kernel_dims = {in.C, out.C};
+        if (!plan_layer(c, L.get())) ok = false;
+        Layer *p = L.get();
+        c->layers.push_back(std::move(L));
+        add_variable(c, p, false);
+        add_variable(c, p, true);
+        Step st;
+        st.name = p->name;
+        st.kernel = "conv_mfma";
+        const double pix = (kind == Layer::DECONV) ? 4.0 * in.H * in.W : (double)out.H * out.W;
+        const double kreal = (kind == Layer::DECONV) ? 4.0 * in.C : (double)p->K;
+        st.flops_per_sample = 2.0 * out.C * kreal * pix;
+        st.bytes_per_sample = 4.0 * ((double)in.C * in.H * in.W + (double)out.C * out.H * out.W);
+        st.bytes_fixed = 4.0 * ((double)p->K * p->ncls * out.C + out.C);
+        st.fn = [p](int n, hipStream_t s) { run_layer(p, n, s); };
+        steps->push_back(st);
+        return p;
+    }
+    // helpers.py:70-102
+    Layer *conv(const std::string &name, View in, View out, int k, int stride, int act, const float *scale = nullptr)
+    {
+        return make(name, Layer::CONV, in, out, k, k, stride, stride, act, scale);
+    }
+    // helpers.py:105-153: <name>y = k x 1 stride (s,1), <name>x = 1 x k stride (1,s), both leaky relu
+    void conv2(const std::string &name, View in, View out, int k, int s)
+    {
+        const int Hmid = (in.H + 2 * (k / 2) - k) / s + 1;
+        char key[64];
+        snprintf(key, sizeof key, "tmp_y_%dx%dx%d", out.C, Hmid, in.W);
+        View mid = buffer(c, key, out.C, Hmid, in.W);
+        make(name + "y", Layer::CONV, in, mid, k, 1, s, 1, 1);
+        make(name + "x", Layer::CONV, mid, out, 1, k, 1, s, 1);
+    }
+    // blocks_original.py:97-110 (lrelu) and :64-75 (linear)
+    Layer *deconv(const std::string &name, View in, View out, int act) { return make(name, Layer::DECONV, in, out, 4, 4, 2, 2, act); }
+    Layer *dense(const std::string &name, View in, View out, int act) { return make(name, Layer::DENSE, in, out, 1, 1, 1, 1, act); }
+    void op(const std::string &name, const std::string &kernel, double bytes_per_sample, std::function<void(int, hipStream_t)> fn)
+    {
+        Step st;
+        st.name = scope + "/" + name;
+        st.kernel = kernel;
+        st.bytes_per_sample = bytes_per_sample;
+        st.fn = std::move(fn);
+        steps->push_back(st);
+    }
+};
+
+// shared encoder/decoder tail of the flow and depth+motion blocks
+struct EncDec {
+    View conv2cat, concat2, concat3, concat4, conv5_1;
+};
+
+// blocks_original.py:121-235
+void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, bool iterative)
+{
+    Builder b{c, steps, scope};
+    const int H = c->H, W = c->W, h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8, h4 = H / 16,
+              w4 = W / 16, h5 = H / 32, w5 = W / 32;
+    View conv1 = buffer(c, "conv1", 32, h1, w1);
+    View conv2cat = buffer(c, "conv2cat", 64, h2, w2);
+    View concat2 = buffer(c, "concat2", 128, h2, w2);
+    View concat3 = buffer(c, "concat3", 256, h3, w3);
+    View concat4f = buffer(c, "concat4_flow", 514, h4, w4);
+    View conv3 = buffer(c, "conv3", 128, h3, w3), conv4 = buffer(c, "conv4", 256, h4, w4);
+    View conv5 = buffer(c, "conv5", 512, h5, w5), conv5_1 = buffer(c, "conv5_1", 512, h5, w5);
+    b.conv2("conv1", c->image_pair, conv1, 9, 2);
+    if (!iterative) {
+        b.conv2("conv2", conv1, conv2cat, 7, 2);  // 64 outputs (:144)
+    } else {
+        b.conv2("conv2", conv1, conv2cat.slice(0, 32), 7, 2);
+        View extra = buffer(c, "extra_flow", 9, h2, w2);  // [warped 3, flow 2, depth 1, normal 3] (:180)
+        View img2 = c->image2_2, depth2 = c->depth2, normal2 = c->normal2;
+        float *rot = c->d_rot, *trans = c->d_trans, *intr = c->d_intrinsics;
+        const double px = (double)h2 * w2 * 4;
+        b.op("depth_to_flow", "depth_to_flow", px * 3, [=](int n, hipStream_t s) {
+            launch_depth_to_flow(extra.slice(3, 2).ptr(), depth2.ptr(), depth2.n_stride(), intr, rot, trans, n, h2, w2,
+                                 extra.n_stride(), 1, 1, 1, s);
+        });
+        b.op("warp2d", "warp2d", px * 8, [=](int n, hipStream_t s) {
+            launch_warp2d(extra.ptr(), extra.n_stride(), img2.ptr(), img2.n_stride(), extra.slice(3, 2).ptr(),
+                          extra.n_stride(), n, 3, h2, w2, 1, 1, 0.0f, s);
+        });
+        b.op("concat_prev", "copy_channels", px * 8, [=](int n, hipStream_t s) {
+            launch_copy_channels(extra.slice(5, 1).ptr(), extra.n_stride(), depth2.ptr(), depth2.n_stride(), n, 1,
+                                 (long)h2 * w2, s);
+            launch_copy_channels(extra.slice(6, 3).ptr(), extra.n_stride(), normal2.ptr(), normal2.n_stride(), n, 3,
+                                 (long)h2 * w2, s);
+        });
+        b.conv2("conv2_extra_inputs", extra, conv2cat.slice(32, 32), 3, 1);
+    }
+    b.conv2("conv2_1", conv2cat, concat2.slice(64, 64), 3, 1);
+    b.conv2("conv3", concat2.slice(64, 64), conv3, 5, 2);
+    b.conv2("conv3_1", conv3, concat3.slice(128, 128), 3, 1);
+    b.conv2("conv4", concat3.slice(128, 128), conv4, 5, 2);
+    b.conv2("conv4_1", conv4, concat4f.slice(256, 256), 3, 1);
+    b.conv2("conv5", concat4f.slice(256, 256), conv5, 5, 2);
+    b.conv2("conv5_1", conv5, conv5_1, 3, 1);
+    View pf5 = buffer(c, "predict5_tmp", 24, h5, w5);
+    b.conv("predict_flow5/conv1", conv5_1, pf5, 3, 1, 1);
+    b.conv("predict_flow5/conv2", pf5, c->flowconf5, 3, 1, 0);
+    b.deconv("upsample_flow5to4/upconv", c->flowconf5, concat4f.slice(512, 2), 0);
+    b.deconv("refine4/upconv", conv5_1, concat4f.slice(0, 256), 1);
+    b.deconv("refine3/upconv", concat4f, concat3.slice(0, 128), 1);
+    b.deconv("refine2/upconv", concat3, concat2.slice(0, 64), 1);
+    View pf2 = buffer(c, "predict2_tmp", 24, h2, w2);
+    b.conv("predict_flow2/conv1", concat2, pf2, 3, 1, 1);
+    b.conv("predict_flow2/conv2", pf2, c->flowconf2, 3, 1, 0);
+    if (!b.ok) c->err = "device allocation failed while building " + scope;
+}
+
+// blocks_original.py:299-448
+void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, bool iterative)
+{
+    Builder b{c, steps, scope};
+    const int H = c->H, W = c->W, h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8, h4 = H / 16,
+              w4 = W / 16, h5 = H / 32, w5 = W / 32;
+    View conv1 = buffer(c, "conv1", 32, h1, w1);
+    View conv2cat = buffer(c, "conv2cat", 64, h2, w2);
+    View concat2 = buffer(c, "concat2", 128, h2, w2);
+    View concat3 = buffer(c, "concat3", 256, h3, w3);
+    View concat4 = buffer(c, "concat4_dm", 512, h4, w4);
+    View conv3 = buffer(c, "conv3", 128, h3, w3), conv4 = buffer(c, "conv4", 256, h4, w4);
+    View conv5 = buffer(c, "conv5", 512, h5, w5), conv5_1 = buffer(c, "conv5_1", 512, h5, w5);
+    b.conv2("conv1", c->image_pair, conv1, 9, 2);
+    b.conv2("conv2", conv1, conv2cat.slice(0, 32), 7, 2);
+    const int nextra = iterative ? 8 : 7;  // [warped 3, flowconf 4, depth_from_flow 1] (:341, :362)
+    View extra = buffer(c, iterative ? "extra_dm8" : "extra_dm7", nextra, h2, w2);
+    View img2 = c->image2_2, flowconf2 = c->flowconf2;
+    const double px = (double)h2 * w2 * 4;
+    b.op("warp2d", "warp2d", px * 8, [=](int n, hipStream_t s) {
+        launch_warp2d(extra.ptr(), extra.n_stride(), img2.ptr(), img2.n_stride(), flowconf2.ptr(), flowconf2.n_stride(), n,
+                      3, h2, w2, 1, 1, 0.0f, s);
+    });
+    b.op("concat_flowconf", "copy_channels", px * 8, [=](int n, hipStream_t s) {
+        launch_copy_channels(extra.slice(3, 4).ptr(), extra.n_stride(), flowconf2.ptr(), flowconf2.n_stride(), n, 4,
+                             (long)h2 * w2, s);
+    });
+    if (iterative) {
+        float *rot = c->d_rot, *trans = c->d_trans, *intr = c->d_intrinsics;
+        demon_ctx *cc = c;
+        b.op("flow_to_depth", "flow_to_depth", px * 3, [=](int n, hipStream_t s) {
+            launch_flow_to_depth(extra.slice(7, 1).ptr(), extra.n_stride(), flowconf2.ptr(), flowconf2.n_stride(), intr,
+                                 rot, trans, n, h2, w2, 1, 1, cc->opt_f2d_method, s);
+        });
+    }
+    b.conv2("conv2_extra_inputs", extra, conv2cat.slice(32, 32), 3, 1);
+    b.conv2("conv2_1", conv2cat, concat2.slice(64, 64), 3, 1);
+    b.conv2("conv3", concat2.slice(64, 64), conv3, 5, 2);
+    b.conv2("conv3_1", conv3, concat3.slice(128, 128), 3, 1);
+    b.conv2("conv4", concat3.slice(128, 128), conv4, 5, 2);
+    b.conv2("conv4_1", conv4, concat4.slice(256, 256), 3, 1);
+    b.conv2("conv5", concat4.slice(256, 256), conv5, 3, 2);  // k = 3 (:375)
+    b.conv2("conv5_1", conv5, conv5_1, 3, 1);
+    // motion head (:380-412); flatten is C,H,W order = NCHW memory order
+    View mconv = buffer(c, "motion_conv1", 128, h5, w5);
+    b.conv("motion_conv1", conv5_1, mconv, 3, 1, 1);
+    View fc_in = mconv;
+    fc_in.C = fc_in.Ctot = 128 * h5 * w5; fc_in.H = fc_in.W = 1;
+    View fc1 = buffer(c, "motion_fc1", 1024, 1, 1), fc2 = buffer(c, "motion_fc2", 128, 1, 1);
+    View fc3;
+    fc3.base = c->d_motion; fc3.Ctot = fc3.C = 7; fc3.c0 = 0; fc3.H = fc3.W = 1;
+    b.dense("motion_fc1", fc_in, fc1, 1);
+    b.dense("motion_fc2", fc1, fc2, 1);
+    b.dense("motion_fc3", fc2, fc3, 0);
+    {
+        float *motion = c->d_motion, *rot = c->d_rot, *trans = c->d_trans, *scale = c->d_scale;
+        b.op("split_motion", "split_motion", 56, [=](int n, hipStream_t s) { launch_split_motion(motion, rot, trans, scale, n, s); });
+    }
+    b.deconv("refine4/upconv", conv5_1, concat4.slice(0, 256), 1);
+    b.deconv("refine3/upconv", concat4, concat3.slice(0, 128), 1);
+    b.deconv("refine2/upconv", concat3, concat2.slice(0, 64), 1);
+    View pd = buffer(c, "predict2_tmp", 24, h2, w2);
+    View dn = buffer(c, "depthnormal2", 4, h2, w2);  // ch 0 = scale*depth, ch 1:4 = normal (:278-287)
+    b.conv("predict_depthnormal2/conv1", concat2, pd, 3, 1, 1);
+    b.conv("predict_depthnormal2/conv2", pd, dn, 3, 1, 0, c->d_scale);
+    if (!b.ok) c->err = "device allocation failed while building " + scope;
+}
+
+// blocks_original.py:452-513
+void build_refine(demon_ctx *c, std::vector<Step> *steps)
+{
+    Builder b{c, steps, "netRefine"};
+    const int H = c->H, W = c->W, h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4;
+    View inp = buffer(c, "refine_in", 4, H, W);  // [image1 3, depth2 upsampled 1] (:482)
+    View concat0 = buffer(c, "refine_concat0", 64, H, W);
+    View concat1 = buffer(c, "refine_concat1", 128, h1, w1);
+    View r1 = buffer(c, "refine_conv1", 64, h1, w1), r2 = buffer(c, "refine_conv2", 128, h2, w2),
+         r2_1 = buffer(c, "refine_conv2_1", 128, h2, w2);
+    View image_pair = c->image_pair, depth2 = c->depth2;
+    b.op("assemble_input", "upsample_nearest", 4.0 * (4.0 * H * W + 3.0 * H * W + h2 * w2), [=](int n, hipStream_t s) {
+        launch_copy_channels(inp.ptr(), inp.n_stride(), image_pair.ptr(), image_pair.n_stride(), n, 3, (long)H * W, s);
+        launch_upsample_nearest(inp.slice(3, 1).ptr(), inp.n_stride(), depth2.ptr(), depth2.n_stride(), n, 1, h2, w2, 4, s);
+    });
+    b.conv("conv0", inp, concat0.slice(32, 32), 3, 1, 1);
+    b.conv("conv1", concat0.slice(32, 32), r1, 3, 2, 1);
+    b.conv("conv1_1", r1, concat1.slice(64, 64), 3, 1, 1);
+    b.conv("conv2", concat1.slice(64, 64), r2, 3, 2, 1);
+    b.conv("conv2_1", r2, r2_1, 3, 1, 1);
+    b.deconv("refine1/upconv", r2_1, concat1.slice(0, 64), 1);
+    b.deconv("refine0/upconv", concat1, concat0.slice(0, 32), 1);
+    View p0 = buffer(c, "predict0_tmp", 16, H, W);
+    b.conv("predict_depth0/conv1", concat0, p0, 3, 1, 1);
+    b.conv("predict_depth0/conv2", p0, c->depth0, 3, 1, 0);
+    if (!b.ok) c->err = "device allocation failed while building netRefine";
+}
+
+bool weights_ready(demon_ctx *c, std::string *missing)
+{
+    for (auto &L : c->layers)
+        if (!L->have_kernel || !L->have_bias) {
+            if (missing) *missing = L->name;
+            return false;
+        }
+    return true;
+}
+
+void run_steps(const std::vector<Step> &steps, int n, hipStream_t s)
+{
+    for (const Step &st : steps) st.fn(n, s);
+}
+
+enum SeqKind { SEQ_BOOT = 0, SEQ_ITER, SEQ_REFINE, SEQ_FULL };
+
+void enqueue_sequence(demon_ctx *c, int kind, int n, int iterations, hipStream_t s)
+{
+    if (kind == SEQ_BOOT || kind == SEQ_FULL) run_steps(c->net_boot, n, s);
+    if (kind == SEQ_ITER) run_steps(c->net_iter, n, s);
+    if (kind == SEQ_FULL)
+        for (int i = 0; i < iterations; ++i) run_steps(c->net_iter, n, s);
+    if (kind == SEQ_REFINE || kind == SEQ_FULL) run_steps(c->net_refine, n, s);
+}
+
+// one hipGraph per (sequence, batch, iterations): the whole kernel chain becomes a single launch
+int run_sequence(demon_ctx *c, int kind, int n, int iterations)
+{
+    if (!c->opt_hipgraph) {
+        enqueue_sequence(c, kind, n, iterations, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        return DEMON_OK;
+    }
+    char key[64];
+    snprintf(key, sizeof key, "%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method);
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        enqueue_sequence(c, kind, n, iterations, c->stream);
+        HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
+        HIP_TRY(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        it = c->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(c, hipGraphLaunch(it->second, c->stream));
+    return DEMON_OK;
+}
+
+int check_batch(demon_ctx *c, int n)
+{
+    if (!c) return DEMON_ERR_INVALID;
+    if (n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "batch size out of range [1, max_batch]");
+    std::string missing;
+    if (!weights_ready(c, &missing)) return fail(c, DEMON_ERR_NOT_READY, "weights not set for layer " + missing);
+    return DEMON_OK;
+}
+
+int h2d(demon_ctx *c, const View &v, const float *host, int n)
+{
+    if (!host) return fail(c, DEMON_ERR_INVALID, "null input pointer");
+    const size_t row = sizeof(float) * (size_t)v.C * v.H * v.W;
+    HIP_TRY(c, hipMemcpy2DAsync(v.ptr(), sizeof(float) * v.n_stride(), host, row, row, n, hipMemcpyHostToDevice, c->stream));
+    return DEMON_OK;
+}
+
+int d2h(demon_ctx *c, float *host, const View &v, int n)
+{
+    if (!host) return DEMON_OK;
+    const size_t row = sizeof(float) * (size_t)v.C * v.H * v.W;
+    HIP_TRY(c, hipMemcpy2DAsync(host, row, v.ptr(), sizeof(float) * v.n_stride(), row, n, hipMemcpyDeviceToHost, c->stream));
+    return DEMON_OK;
+}
+
+int download_outputs(demon_ctx *c, int n, const demon_outputs *o)
+{
+    if (!o) return DEMON_OK;
+    int r;
+    if ((r = d2h(c, o->predict_flow5, c->flowconf5.slice(0, 2), n))) return r;
+    if ((r = d2h(c, o->predict_conf5, c->flowconf5.slice(2, 2), n))) return r;
+    if ((r = d2h(c, o->predict_flow2, c->flowconf2.slice(0, 2), n))) return r;
+    if ((r = d2h(c, o->predict_conf2, c->flowconf2.slice(2, 2), n))) return r;
+    if ((r = d2h(c, o->predict_depth2, c->depth2, n))) return r;
+    if ((r = d2h(c, o->predict_normal2, c->normal2, n))) return r;
+    if (o->predict_rotation) HIP_TRY(c, hipMemcpyAsync(o->predict_rotation, c->d_rot, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    if (o->predict_translation) HIP_TRY(c, hipMemcpyAsync(o->predict_translation, c->d_trans, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+    if (o->predict_scale) HIP_TRY(c, hipMemcpyAsync(o->predict_scale, c->d_scale, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    return DEMON_OK;
+}
+
+struct TmpDev {
+    std::vector<void *> ptrs;
+    ~TmpDev() { for (void *p : ptrs) hipFree(p); }
+    float *alloc(size_t nfloats)
+    {
+        void *p = nullptr;
+        if (hipMalloc(&p, sizeof(float) * (nfloats ? nfloats : 4)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (float *)p;
+    }
+    float *upload(const float *h, size_t nfloats)
+    {
+        float *d = alloc(nfloats);
+        if (d && hipMemcpy(d, h, sizeof(float) * nfloats, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    }
+};
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int demon_create(demon_ctx **out, int device, int max_batch, int height, int width)
+{
+    if (!out) return fail(nullptr, DEMON_ERR_INVALID, "null ctx pointer");
+    *out = nullptr;
+    if (max_batch < 1 || height < 32 || width < 32 || height % 32 || width % 32)
+        return fail(nullptr, DEMON_ERR_INVALID, "max_batch must be >= 1 and height/width positive multiples of 32");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, DEMON_ERR_HIP, "no HIP device visible (libdemon_hip.so needs an MI355X / gfx950 GPU)");
+    if (device < 0 || device >= ndev) return fail(nullptr, DEMON_ERR_INVALID, "device index out of range");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, DEMON_ERR_HIP, "hipSetDevice failed");
+    std::unique_ptr<demon_ctx> c(new demon_ctx);
+    c->device = device; c->max_batch = max_batch; c->H = height; c->W = width;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        return fail(nullptr, DEMON_ERR_HIP, "hipStreamCreate failed");
+    demon_ctx *p = c.get();
+    const int h2 = height / 4, w2 = width / 4, h5 = height / 32, w5 = width / 32;
+    p->image_pair = buffer(p, "image_pair", 6, height, width);
+    p->image2_2 = buffer(p, "image2_2", 3, h2, w2);
+    p->flowconf5 = buffer(p, "flowconf5", 4, h5, w5);
+    p->flowconf2 = buffer(p, "flowconf2", 4, h2, w2);
+    // the depth+normal head writes [depth, normal xyz] into one 4-channel buffer; the state the next
+    // stage reads (prev depth2 / normal2, blocks_original.py:180) are slices of it, so nothing is copied
+    p->depth2 = buffer(p, "depthnormal2", 4, h2, w2).slice(0, 1);
+    p->normal2 = buffer(p, "depthnormal2", 4, h2, w2).slice(1, 3);
+    p->depth0 = buffer(p, "depth0", 1, height, width);
+    p->d_rot = dev_alloc(p, sizeof(float) * 3 * max_batch);
+    p->d_trans = dev_alloc(p, sizeof(float) * 3 * max_batch);
+    p->d_scale = dev_alloc(p, sizeof(float) * max_batch);
+    p->d_motion = dev_alloc(p, sizeof(float) * 7 * max_batch);
+    p->d_intrinsics = dev_alloc(p, sizeof(float) * 4 * max_batch);
+    if (!p->d_rot || !p->d_trans || !p->d_scale || !p->d_motion || !p->d_intrinsics) {
+        demon_destroy(c.release());
+        return fail(nullptr, DEMON_ERR_HIP, "device allocation failed");
+    }
+    {
+        // networks_original.py:108-109
+        std::vector<float> intr((size_t)4 * max_batch);
+        for (int i = 0; i < max_batch; ++i) {
+            intr[4 * i + 0] = 0.89115971f; intr[4 * i + 1] = 1.18821287f; intr[4 * i + 2] = 0.5f; intr[4 * i + 3] = 0.5f;
+        }
+        hipMemcpy(p->d_intrinsics, intr.data(), intr.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+    build_flow(p, &p->net_boot, "netFlow1", false);
+    build_dm(p, &p->net_boot, "netDM1", false);
+    build_flow(p, &p->net_iter, "netFlow2", true);
+    build_dm(p, &p->net_iter, "netDM2", true);
+    build_refine(p, &p->net_refine);
+    if (!p->err.empty() || hipDeviceSynchronize() != hipSuccess) {
+        std::string e = p->err.empty() ? "device error while building the networks" : p->err;
+        demon_destroy(c.release());
+        return fail(nullptr, DEMON_ERR_HIP, e);
+    }
+    *out = c.release();
+    return DEMON_OK;
+}
+
+int demon_destroy(demon_ctx *c)
+{
+    if (!c) return DEMON_OK;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+    for (void *p : c->allocations) hipFree(p);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return DEMON_OK;
+}
+
+const char *demon_last_error(const demon_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+int demon_device(const demon_ctx *c) { return c ? c->device : -1; }
+
+int demon_num_variables(const demon_ctx *c) { return c ? (int)c->variables.size() : 0; }
+
+int demon_variable_info(const demon_ctx *c, int index, char *name, int name_cap, int64_t dims[4], int *ndim)
+{
+    if (!c || index < 0 || index >= (int)c->variables.size()) return DEMON_ERR_INVALID;
+    const Variable &v = c->variables[index];
+    if (name && name_cap > 0) { strncpy(name, v.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    for (int i = 0; i < 4; ++i) dims[i] = i < v.ndim ? v.dims[i] : 1;
+    if (ndim) *ndim = v.ndim;
+    return DEMON_OK;
+}
+
+int demon_set_weight(demon_ctx *c, const char *tf_name, const float *host, const int64_t *dims, int ndim)
+{
+    if (!c || !tf_name || !host) return fail(c, DEMON_ERR_INVALID, "null argument");
+    auto it = c->var_index.find(tf_name);
+    if (it == c->var_index.end()) return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown variable ") + tf_name);
+    const Variable &v = c->variables[it->second];
+    if (dims) {
+        bool same = ndim == v.ndim;
+        for (int i = 0; same && i < ndim; ++i) same = dims[i] == v.dims[i];
+        if (!same) return fail(c, DEMON_ERR_INVALID, std::string("shape mismatch for variable ") + tf_name);
+    }
+    hipSetDevice(c->device);
+    for (auto &g : c->graphs) hipGraphExecDestroy(g.second);  // packed pointers stay, but be safe
+    c->graphs.clear();
+    if (v.is_bias) {
+        HIP_TRY(c, hipMemcpy(v.layer->d_bias, host, sizeof(float) * v.layer->Cout, hipMemcpyHostToDevice));
+        v.layer->have_bias = true;
+        return DEMON_OK;
+    }
+    return upload_kernel(c, v.layer, host);
+}
+
+int64_t demon_weights_blob_size(const demon_ctx *c)
+{
+    if (!c) return 0;
+    int64_t total = 0;
+    for (const Variable &v : c->variables) total += v.count;
+    return total;
+}
+
+int demon_set_weights_blob(demon_ctx *c, const float *blob, int64_t nfloats)
+{
+    if (!c || !blob) return fail(c, DEMON_ERR_INVALID, "null argument");
+    if (nfloats != demon_weights_blob_size(c)) return fail(c, DEMON_ERR_INVALID, "weight blob size mismatch");
+    int64_t off = 0;
+    for (const Variable &v : c->variables) {
+        int r = demon_set_weight(c, v.name.c_str(), blob + off, v.dims, v.ndim);
+        if (r) return r;
+        off += v.count;
+    }
+    return DEMON_OK;
+}
+
+int demon_set_weights_blob_device(demon_ctx *c, const void *dblob, int64_t nfloats)
+{
+    if (!c || !dblob) return fail(c, DEMON_ERR_INVALID, "null argument");
+    if (nfloats != demon_weights_blob_size(c)) return fail(c, DEMON_ERR_INVALID, "weight blob size mismatch");
+    hipSetDevice(c->device);
+    std::vector<float> host((size_t)nfloats);
+    HIP_TRY(c, hipMemcpy(host.data(), dblob, sizeof(float) * (size_t)nfloats, hipMemcpyDeviceToHost));
+    return demon_set_weights_blob(c, host.data(), nfloats);
+}
+
+int demon_set_option(demon_ctx *c, const char *key, int value)
+{
+    if (!c || !key) return DEMON_ERR_INVALID;
+    if (!strcmp(key, "hipgraph")) { c->opt_hipgraph = value ? 1 : 0; return DEMON_OK; }
+    if (!strcmp(key, "flow_to_depth_method")) {
+        if (value != 0 && value != 1) return fail(c, DEMON_ERR_INVALID, "flow_to_depth_method must be 0 or 1");
+        c->opt_f2d_method = value;
+        return DEMON_OK;
+    }
+    return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
+}
+
+int demon_upload_inputs(demon_ctx *c, int n, const float *image_pair, const float *image2_2)
+{
+    int r = check_batch(c, n);
+    if (r) return r;
+    hipSetDevice(c->device);
+    if ((r = h2d(c, c->image_pair, image_pair, n))) return r;
+    if ((r = h2d(c, c->image2_2, image2_2, n))) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DEMON_OK;
+}
+
+int demon_run_full(demon_ctx *c, int n, int iterations)
+{
+    int r = check_batch(c, n);
+    if (r) return r;
+    if (iterations < 0 || iterations > 64) return fail(c, DEMON_ERR_INVALID, "iterations out of range");
+    hipSetDevice(c->device);
+    return run_sequence(c, SEQ_FULL, n, iterations);
+}
+
+int demon_run_bootstrap(demon_ctx *c, int n)
+{
+    int r = check_batch(c, n);
+    if (r) return r;
+    hipSetDevice(c->device);
+    return run_sequence(c, SEQ_BOOT, n, 0);
+}
+
+int demon_synchronize(demon_ctx *c)
+{
+    if (!c) return DEMON_ERR_INVALID;
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DEMON_OK;
+}
+
+int demon_download_outputs(demon_ctx *c, int n, const demon_outputs *o, float *depth0)
+{
+    if (!c || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad batch");
+    hipSetDevice(c->device);
+    int r = download_outputs(c, n, o);
+    if (r) return r;
+    if ((r = d2h(c, depth0, c->depth0, n))) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DEMON_OK;
+}
+
+int demon_bootstrap(demon_ctx *c, int n, const float *image_pair, const float *image2_2, const demon_outputs *o)
+{
+    int r = demon_upload_inputs(c, n, image_pair, image2_2);
+    if (r) return r;
+    if ((r = run_sequence(c, SEQ_BOOT, n, 0))) return r;
+    return demon_download_outputs(c, n, o, nullptr);
+}
+
+int demon_iterative(demon_ctx *c, int n, const float *image_pair, const float *image2_2, const float *depth2,
+                    const float *normal2, const float *rotation, const float *translation, const demon_outputs *o)
+{
+    int r = demon_upload_inputs(c, n, image_pair, image2_2);
+    if (r) return r;
+    if (!rotation || !translation) return fail(c, DEMON_ERR_INVALID, "null input pointer");
+    if ((r = h2d(c, c->depth2, depth2, n))) return r;
+    if ((r = h2d(c, c->normal2, normal2, n))) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->d_rot, rotation, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_trans, translation, sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((r = run_sequence(c, SEQ_ITER, n, 0))) return r;
+    return demon_download_outputs(c, n, o, nullptr);
+}
+
+int demon_refine(demon_ctx *c, int n, const float *image1, const float *depth2, float *depth0)
+{
+    int r = check_batch(c, n);
+    if (r) return r;
+    hipSetDevice(c->device);
+    if ((r = h2d(c, c->image_pair.slice(0, 3), image1, n))) return r;
+    if ((r = h2d(c, c->depth2, depth2, n))) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((r = run_sequence(c, SEQ_REFINE, n, 0))) return r;
+    return demon_download_outputs(c, n, nullptr, depth0);
+}
+
+int demon_full(demon_ctx *c, int n, const float *image_pair, const float *image2_2, int iterations,
+               const demon_outputs *o, float *depth0)
+{
+    int r = demon_upload_inputs(c, n, image_pair, image2_2);
+    if (r) return r;
+    if (iterations < 0 || iterations > 64) return fail(c, DEMON_ERR_INVALID, "iterations out of range");
+    if ((r = run_sequence(c, SEQ_FULL, n, iterations))) return r;
+    return demon_download_outputs(c, n, o, depth0);
+}
+
+int demon_time_full(demon_ctx *c, int n, int iterations, int steps, float *total_ms)
+{
+    int r = check_batch(c, n);
+    if (r) return r;
+    if (steps < 1 || !total_ms) return fail(c, DEMON_ERR_INVALID, "bad steps");
+    hipSetDevice(c->device);
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < steps; ++i)
+        if ((r = run_sequence(c, SEQ_FULL, n, iterations))) return r;
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    HIP_TRY(c, hipEventElapsedTime(total_ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return DEMON_OK;
+}
+
+int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_launch_record *rec, int cap, int *count)
+{
+    int r = check_batch(c, n);
+    if (r) return r;
+    if (repeats < 1 || !rec || !count) return fail(c, DEMON_ERR_INVALID, "bad arguments");
+    hipSetDevice(c->device);
+    std::vector<const Step *> seq;
+    for (auto &s : c->net_boot) seq.push_back(&s);
+    for (int i = 0; i < iterations; ++i)
+        for (auto &s : c->net_iter) seq.push_back(&s);
+    for (auto &s : c->net_refine) seq.push_back(&s);
+    std::vector<hipEvent_t> ev(2 * seq.size());
+    for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
+    std::vector<double> ms(seq.size(), 0.0);
+    for (int rep = 0; rep < repeats + 1; ++rep) {  // first pass = warm-up
+        for (size_t i = 0; i < seq.size(); ++i) {
+            HIP_TRY(c, hipEventRecord(ev[2 * i], c->stream));
+            seq[i]->fn(n, c->stream);
+            HIP_TRY(c, hipEventRecord(ev[2 * i + 1], c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (rep == 0) continue;
+        for (size_t i = 0; i < seq.size(); ++i) {
+            float t = 0;
+            HIP_TRY(c, hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+            ms[i] += t;
+        }
+    }
+    for (auto &e : ev) hipEventDestroy(e);
+    *count = (int)seq.size();
+    for (size_t i = 0; i < seq.size() && (int)i < cap; ++i) {
+        memset(&rec[i], 0, sizeof rec[i]);
+        strncpy(rec[i].name, seq[i]->name.c_str(), sizeof rec[i].name - 1);
+        strncpy(rec[i].kernel, seq[i]->kernel.c_str(), sizeof rec[i].kernel - 1);
+        rec[i].flops = seq[i]->flops_per_sample * n;
+        rec[i].bytes = seq[i]->bytes_per_sample * n + seq[i]->bytes_fixed;
+        rec[i].ms = (float)(ms[i] / repeats);
+    }
+    return DEMON_OK;
+}
+
+// ---- op-level entry points -----------------------------------------------------------------------------
+#define OP_PROLOGUE(c)                                   \
+    if (!(c)) return DEMON_ERR_INVALID;                  \
+    hipSetDevice((c)->device);                           \
+    TmpDev tmp;
+
+#define OP_FINISH(c, dptr, hptr, nfloats)                                                                         \
+    HIP_TRY(c, hipGetLastError());                                                                                \
+    HIP_TRY(c, hipStreamSynchronize((c)->stream));                                                                \
+    HIP_TRY(c, hipMemcpy(hptr, dptr, sizeof(float) * (size_t)(nfloats), hipMemcpyDeviceToHost));                  \
+    return DEMON_OK;
+
+int demon_op_depth_to_flow(demon_ctx *c, float *out, const float *depth, const float *intrinsics, const float *rotation,
+                           const float *translation, int n, int h, int w, int inverse_depth, int normalize_flow, int gate)
+{
+    OP_PROLOGUE(c);
+    if (!out || !depth || !intrinsics || !rotation || !translation || n < 1 || h < 1 || w < 1)
+        return fail(c, DEMON_ERR_INVALID, "bad argument");
+    const size_t hw = (size_t)h * w;
+    float *d_depth = tmp.upload(depth, n * hw), *d_k = tmp.upload(intrinsics, 4 * n), *d_r = tmp.upload(rotation, 3 * n),
+          *d_t = tmp.upload(translation, 3 * n), *d_out = tmp.alloc(2 * n * hw);
+    if (!d_depth || !d_k || !d_r || !d_t || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    launch_depth_to_flow(d_out, d_depth, hw, d_k, d_r, d_t, n, h, w, 2 * hw, inverse_depth, normalize_flow, gate, c->stream);
+    OP_FINISH(c, d_out, out, 2 * n * hw);
+}
+
+int demon_op_flow_to_depth(demon_ctx *c, float *out, const float *flow, const float *intrinsics, const float *rotation,
+                           const float *translation, int n, int h, int w, int inverse_depth, int normalized_flow, int method)
+{
+    OP_PROLOGUE(c);
+    if (!out || !flow || !intrinsics || !rotation || !translation || n < 1 || h < 1 || w < 1 || method < 0 || method > 1)
+        return fail(c, DEMON_ERR_INVALID, "bad argument");
+    const size_t hw = (size_t)h * w;
+    float *d_flow = tmp.upload(flow, 2 * n * hw), *d_k = tmp.upload(intrinsics, 4 * n), *d_r = tmp.upload(rotation, 3 * n),
+          *d_t = tmp.upload(translation, 3 * n), *d_out = tmp.alloc(n * hw);
+    if (!d_flow || !d_k || !d_r || !d_t || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    launch_flow_to_depth(d_out, hw, d_flow, 2 * hw, d_k, d_r, d_t, n, h, w, inverse_depth, normalized_flow, method, c->stream);
+    OP_FINISH(c, d_out, out, n * hw);
+}
+
+int demon_op_warp2d(demon_ctx *c, float *out, const float *input, const float *disp, int n, int ch, int h, int w,
+                    int normalized, int border_mode, float border_value)
+{
+    OP_PROLOGUE(c);
+    if (!out || !input || !disp || n < 1 || ch < 1 || h < 1 || w < 1) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    const size_t hw = (size_t)h * w;
+    float *d_in = tmp.upload(input, n * ch * hw), *d_disp = tmp.upload(disp, 2 * n * hw), *d_out = tmp.alloc(n * ch * hw);
+    if (!d_in || !d_disp || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    launch_warp2d(d_out, ch * hw, d_in, ch * hw, d_disp, 2 * hw, n, ch, h, w, normalized, border_mode, border_value, c->stream);
+    OP_FINISH(c, d_out, out, n * ch * hw);
+}
+
+int demon_op_leaky_relu(demon_ctx *c, float *out, const float *in, int64_t count, float leak)
+{
+    OP_PROLOGUE(c);
+    if (!out || !in || count < 0) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (count == 0) return DEMON_OK;
+    float *d_in = tmp.upload(in, count), *d_out = tmp.alloc(count);
+    if (!d_in || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    launch_leaky_relu(d_out, d_in, count, leak, c->stream);
+    OP_FINISH(c, d_out, out, count);
+}
+
+int demon_op_replace_nonfinite(demon_ctx *c, float *out, const float *in, int64_t count, float value)
+{
+    OP_PROLOGUE(c);
+    if (!out || !in || count < 0) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (count == 0) return DEMON_OK;
+    float *d_in = tmp.upload(in, count), *d_out = tmp.alloc(count);
+    if (!d_in || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    launch_replace_nonfinite(d_out, d_in, count, value, c->stream);
+    OP_FINISH(c, d_out, out, count);
+}
+
+int demon_op_scale_invariant_gradient(demon_ctx *c, float *out, const float *in, int nc, int h, int w, const int *deltas,
+                                      const float *weights, int ndeltas, float epsilon)
+{
+    OP_PROLOGUE(c);
+    if (!out || !in || !deltas || !weights || nc < 1 || h < 1 || w < 1 || ndeltas < 1 || ndeltas > 8)
+        return fail(c, DEMON_ERR_INVALID, "bad argument (1..8 deltas)");
+    const size_t hw = (size_t)h * w;
+    float *d_in = tmp.upload(in, nc * hw), *d_out = tmp.alloc(2 * nc * hw);
+    if (!d_in || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    launch_sig(d_out, d_in, nc, h, w, deltas, weights, ndeltas, epsilon, c->stream);
+    OP_FINISH(c, d_out, out, 2 * nc * hw);
+}
+
+int demon_op_median3x3_downsample(demon_ctx *c, float *out, const float *in, int nc, int h, int w)
+{
+    OP_PROLOGUE(c);
+    if (!out || !in || nc < 1 || h < 1 || w < 1) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    const size_t ho = (h + 1) / 2, wo = (w + 1) / 2;
+    float *d_in = tmp.upload(in, (size_t)nc * h * w), *d_out = tmp.alloc(nc * ho * wo);
+    if (!d_in || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    launch_median3x3_downsample(d_out, d_in, nc, h, w, c->stream);
+    OP_FINISH(c, d_out, out, nc * ho * wo);
+}
+
+// one stand-alone contraction layer through the same packing + kernel path the networks use
+static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const float *in, const float *w, const float *bias,
+                            int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw, int lrelu)
+{
+    if (!c) return DEMON_ERR_INVALID;
+    hipSetDevice(c->device);
+    if (!out || !in || !w || !bias || n < 1 || cin < 1 || cout < 1 || h < 1 || wd < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1)
+        return fail(c, DEMON_ERR_INVALID, "bad argument");
+    demon_ctx scratch;  // owns the temporary device allocations of this call
+    scratch.device = c->device;
+    scratch.max_batch = n;
+    Layer L;
+    L.kind = kind; L.Cin = cin; L.Cout = cout; L.kh = kh; L.kw = kw; L.sh = sh; L.sw = sw; L.ph = kh / 2; L.pw = kw / 2;
+    L.act = lrelu;
+    int ho, wo;
+    if (kind == Layer::DECONV) { ho = 2 * h; wo = 2 * wd; }
+    else if (kind == Layer::DENSE) { ho = 1; wo = 1; }
+    else { ho = (h + 2 * L.ph - kh) / sh + 1; wo = (wd + 2 * L.pw - kw) / sw + 1; }
+    L.in = buffer(&scratch, "in", cin, h, wd);
+    L.out = buffer(&scratch, "out", cout, ho, wo);
+    int rc = DEMON_OK;
+    if (!L.in.base || !L.out.base || !plan_layer(&scratch, &L)) rc = fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    if (!rc && upload_kernel(&scratch, &L, w)) rc = fail(c, DEMON_ERR_HIP, scratch.err);
+    if (!rc && hipMemcpy(L.d_bias, bias, sizeof(float) * cout, hipMemcpyHostToDevice) != hipSuccess) rc = fail(c, DEMON_ERR_HIP, "bias upload failed");
+    if (!rc && hipMemcpy(L.in.base, in, sizeof(float) * (size_t)n * cin * h * wd, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(c, DEMON_ERR_HIP, "input upload failed");
+    if (!rc) {
+        run_layer(&L, n, c->stream);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
+            hipMemcpy(out, L.out.base, sizeof(float) * (size_t)n * cout * ho * wo, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(c, DEMON_ERR_HIP, "layer execution failed");
+    }
+    for (void *p : scratch.allocations) hipFree(p);
+    return rc;
+}
+
+int demon_op_conv2d(demon_ctx *c, float *out, const float *in, const float *w_hwio, const float *bias, int n, int cin, int h,
+                    int w, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int lrelu)
+{
+    if (c && (ph != kh / 2 || pw != kw / 2)) return fail(c, DEMON_ERR_INVALID, "only caffe-style padding k/2 is supported (helpers.py:78-79)");
+    return run_single_layer(c, Layer::CONV, out, in, w_hwio, bias, n, cin, h, w, cout, kh, kw, sh, sw, lrelu);
+}
+
+int demon_op_deconv4x4s2(demon_ctx *c, float *out, const float *in, const float *w_hwoi, const float *bias, int n, int cin,
+                         int h, int w, int cout, int lrelu)
+{
+    return run_single_layer(c, Layer::DECONV, out, in, w_hwoi, bias, n, cin, h, w, cout, 4, 4, 2, 2, lrelu);
+}
+
+int demon_op_dense(demon_ctx *c, float *out, const float *in, const float *w_io, const float *bias, int n, int cin, int cout,
+                   int lrelu)
+{
+    return run_single_layer(c, Layer::DENSE, out, in, w_io, bias, n, cin, 1, 1, cout, 1, 1, 1, 1, lrelu);
+}
+
+}  // extern "C"

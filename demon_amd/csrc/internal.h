@@ -1,0 +1,89 @@
+// internal.h -- shared declarations of libdemon_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace demon {
+
+// ---------------------------------------------------------------------------------------------
+// A view of `C` channels [c0, c0+C) inside an NCHW device buffer that has `Ctot` channels per
+// sample.  Writing layer outputs straight into such slices removes every tf.concat of
+// blocks_original.py (:111-117, :183, :186, :364, :366, :482).
+// ---------------------------------------------------------------------------------------------
+struct View {
+    float *base = nullptr;  // start of the underlying buffer
+    int Ctot = 0, c0 = 0, C = 0, H = 0, W = 0;
+    __host__ __device__ long n_stride() const { return (long)Ctot * H * W; }
+    float *ptr() const { return base + (long)c0 * H * W; }
+    View slice(int start, int count) const {
+        View v = *this;
+        v.c0 = c0 + start;
+        v.C = count;
+        return v;
+    }
+};
+
+// One entry of the implicit-GEMM K table: where the B operand element of reduction index k comes
+// from, relative to the output pixel's anchor (y*sy, x*sx) in the input plane.
+struct KEntry {
+    int delta;  // ci*H*W + dy*W + dx   (elements)
+    int dydx;   // (dy << 16) | (dx & 0xffff);  dy = -30000 marks padding rows (k >= K)
+};
+
+// Arguments of the implicit-GEMM convolution kernel (conv_mfma.hip).
+//   D[co][pix] = sum_k Wp[k][co] * X[k][pix],  pix = (n, y, x) on a Hp x Wp pixel grid
+// Plain / separable convs: the pixel grid is the output grid.  4x4 stride-2 transposed convs run
+// as four 2x2 sub-pixel convs (gridDim.z = 4): the pixel grid is the INPUT grid and the output
+// lands at (2y+py, 2x+px).
+struct ConvArgs {
+    const float *in;    // input view base pointer (already offset to channel c0)
+    float *out;         // output view base pointer (already offset to channel c0)
+    const float *wp;    // packed weights [cls][Kpad][Mpad]
+    const float *bias;  // [Mpad]
+    const KEntry *ktab; // [cls][Kpad]
+    const float *scale; // optional per-sample multiplier applied to output channel 0 (depth head), or null
+    int N, H, W;        // input plane geometry
+    long in_n_stride;   // elements between samples of the input buffer
+    int Hp, Wp;         // pixel grid
+    int sy, sx;         // anchor stride: iy0 = y*sy, ix0 = x*sx
+    int Cout, Mpad, Kpad;
+    int Ho, Wo;         // output plane geometry
+    long out_n_stride;  // elements between samples of the output buffer
+    int osy, osx;       // output placement: oy = y*osy + py, ox = x*osx + px
+    int act;            // 1 = leaky relu 0.1
+    long cls_w_stride;  // Kpad*Mpad
+};
+
+enum ConvTile { TILE_128x128 = 0, TILE_64x128, TILE_32x128, TILE_64x64, TILE_32x64, TILE_32x32, TILE_COUNT };
+
+void launch_conv_mfma(const ConvArgs &a, int tile, int nclasses, hipStream_t stream);
+int choose_conv_tile(int Mpad, long pixels, int nclasses);
+
+// ---- op launchers (ops.hip) --------------------------------------------------------------------
+void launch_depth_to_flow(float *out, const float *depth, long depth_n_stride, const float *intrinsics,
+                          const float *rotation, const float *translation, int N, int H, int W,
+                          long out_n_stride, int inverse_depth, int normalize_flow, int gate, hipStream_t s);
+void launch_flow_to_depth(float *out, long out_n_stride, const float *flow, long flow_n_stride,
+                          const float *intrinsics, const float *rotation, const float *translation, int N, int H,
+                          int W, int inverse_depth, int normalized_flow, int method, hipStream_t s);
+void launch_warp2d(float *out, long out_n_stride, const float *in, long in_n_stride, const float *disp,
+                   long disp_n_stride, int N, int C, int H, int W, int normalized, int border_mode,
+                   float border_value, hipStream_t s);
+void launch_leaky_relu(float *out, const float *in, long count, float leak, hipStream_t s);
+void launch_replace_nonfinite(float *out, const float *in, long count, float value, hipStream_t s);
+void launch_sig(float *out, const float *in, int NC, int H, int W, const int *deltas, const float *weights,
+                int ndeltas, float eps, hipStream_t s);
+void launch_median3x3_downsample(float *out, const float *in, int NC, int H, int W, hipStream_t s);
+// copies C channels of a view into another view (same H, W)
+void launch_copy_channels(float *dst, long dst_n_stride, const float *src, long src_n_stride, int N, int C,
+                          long HW, hipStream_t s);
+// nearest-neighbour upsample by an integer factor into a channel slice
+void launch_upsample_nearest(float *dst, long dst_n_stride, const float *src, long src_n_stride, int N, int C,
+                             int H, int W, int factor, hipStream_t s);
+// splits the motion vector [N,7] into rotation [N,3], translation [N,3], scale [N,1]
+void launch_split_motion(const float *motion, float *rot, float *trans, float *scale, int N, hipStream_t s);
+
+}  // namespace demon

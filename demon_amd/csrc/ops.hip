@@ -1,0 +1,452 @@
+// ops.hip -- the lmbspecialops-level kernels of the DeMoN hot path for gfx950.
+//
+// Every kernel maps one 64-lane wavefront onto 64 consecutive pixels of an image row segment so that
+// all streaming loads/stores are 256-byte coalesced; per-sample camera parameters are wave-uniform.
+// Arithmetic is written in the same operation order as the CPU oracle so the two agree to rounding.
+//
+//   depth_to_flow (+ |flow|<1 gate)  blocks_original.py:155-168
+//   flow_to_depth / flow_to_depth2   blocks_original.py:344-360, v2/blocks.py:362-378
+//   warp2d                           blocks_original.py:171-176, :336-339
+//   leaky_relu                       helpers.py:60-63
+//   replace_nonfinite                v2/losses.py:49
+//   scale_invariant_gradient         v2/losses.py:76-79
+//   median3x3_downsample             examples/evaluation.py:173
+#include "internal.h"
+
+namespace demon {
+
+// angle-axis -> rotation matrix, helpers.py:37-57 (identity when angle <= 1e-6)
+__device__ __forceinline__ void angleaxis_to_rotation(const float *__restrict__ aa, float R[9])
+{
+    const float ax = aa[0], ay = aa[1], az = aa[2];
+    const float angle = sqrtf(ax * ax + ay * ay + az * az);
+    if (angle > 1e-6f) {
+        const float c = cosf(angle), s = sinf(angle);
+        const float ux = ax / angle, uy = ay / angle, uz = az / angle;
+        const float omc = 1.0f - c;
+        R[0] = c + ux * ux * omc;      R[1] = ux * uy * omc - uz * s; R[2] = ux * uz * omc + uy * s;
+        R[3] = uy * ux * omc + uz * s; R[4] = c + uy * uy * omc;      R[5] = uy * uz * omc - ux * s;
+        R[6] = uz * ux * omc - uy * s; R[7] = uz * uy * omc + ux * s; R[8] = c + uz * uz * omc;
+    } else {
+        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    }
+}
+
+// grid: (ceil(H*W/256), N)
+__global__ __launch_bounds__(256) void depth_to_flow_kernel(float *__restrict__ out, const float *__restrict__ depth,
+                                                            long depth_n_stride, const float *__restrict__ intrinsics,
+                                                            const float *__restrict__ rotation,
+                                                            const float *__restrict__ translation, int H, int W,
+                                                            long out_n_stride, int inverse_depth, int normalize_flow,
+                                                            int gate)
+{
+    const int n = blockIdx.y;
+    const int hw = H * W;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw) return;
+    const int y = idx / W, x = idx - y * W;
+    const float *K = intrinsics + 4 * n;
+    const float fx = K[0] * W, fy = K[1] * H, cx = K[2] * W, cy = K[3] * H;
+    const float ifx = 1.0f / fx, ify = 1.0f / fy;
+    float R[9];
+    angleaxis_to_rotation(rotation + 3 * n, R);
+    const float *t = translation + 3 * n;
+    float d = depth[(long)n * depth_n_stride + idx];
+    float fxo = __builtin_nanf(""), fyo = __builtin_nanf("");
+    if (inverse_depth) d = 1.0f / d;
+    if (d > 0.0f && isfinite(d)) {
+        const float px = x + 0.5f, py = y + 0.5f;
+        const float X = d * ((px - cx) * ifx), Y = d * ((py - cy) * ify), Z = d;
+        const float X2 = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+        const float Y2 = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+        const float Z2 = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+        const float p2x = fx * X2 / Z2 + cx, p2y = fy * Y2 / Z2 + cy;
+        fxo = p2x - px;
+        fyo = p2y - py;
+        if (normalize_flow) { fxo /= W; fyo /= H; }
+    }
+    if (gate) {
+        const float nrm = sqrtf(fxo * fxo + fyo * fyo);
+        if (!(nrm < 1.0f)) { fxo = 0.0f; fyo = 0.0f; }
+    }
+    float *o = out + (long)n * out_n_stride + idx;
+    o[0] = fxo;
+    o[hw] = fyo;
+}
+
+// One-sided Jacobi SVD of a 4x4 matrix, 8 fixed sweeps; returns the right singular vector of the
+// smallest singular value.  Same operation sequence as jacobi_null4 in oracle/demon_oracle.c.
+__device__ __forceinline__ void jacobi_null4(float A[4][4], float X[4])
+{
+    float V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 8; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                float alpha = 0, beta = 0, gamma = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    alpha += A[i][p] * A[i][p];
+                    beta += A[i][q] * A[i][q];
+                    gamma += A[i][p] * A[i][q];
+                }
+                const bool skip = fabsf(gamma) <= 1e-30f || !(fabsf(gamma) > 1e-12f * sqrtf(alpha * beta));
+                const float zeta = (beta - alpha) / (2.0f * gamma);
+                const float tt = (zeta >= 0 ? 1.0f : -1.0f) / (fabsf(zeta) + sqrtf(1.0f + zeta * zeta));
+                float c = 1.0f / sqrtf(1.0f + tt * tt), s = c * tt;
+                if (skip) { c = 1.0f; s = 0.0f; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float ap = A[i][p], aq = A[i][q];
+                    A[i][p] = skip ? ap : c * ap - s * aq;
+                    A[i][q] = skip ? aq : s * ap + c * aq;
+                    const float vp = V[i][p], vq = V[i][q];
+                    V[i][p] = skip ? vp : c * vp - s * vq;
+                    V[i][q] = skip ? vq : s * vp + c * vq;
+                }
+            }
+    }
+    float bestn = __builtin_inff();
+    X[0] = X[1] = X[2] = X[3] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float nn = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nn += A[i][j] * A[i][j];
+        if (nn < bestn) {
+            bestn = nn;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) X[i] = V[i][j];
+        }
+    }
+}
+
+// grid: (ceil(H*W/256), N)
+__global__ __launch_bounds__(256) void flow_to_depth_kernel(float *__restrict__ out, long out_n_stride,
+                                                            const float *__restrict__ flow, long flow_n_stride,
+                                                            const float *__restrict__ intrinsics,
+                                                            const float *__restrict__ rotation,
+                                                            const float *__restrict__ translation, int H, int W,
+                                                            int inverse_depth, int normalized_flow, int method)
+{
+    const int n = blockIdx.y;
+    const int hw = H * W;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw) return;
+    const int y = idx / W, x = idx - y * W;
+    const float *K = intrinsics + 4 * n;
+    const float fx = K[0] * W, fy = K[1] * H, cx = K[2] * W, cy = K[3] * H;
+    float R[9];
+    angleaxis_to_rotation(rotation + 3 * n, R);
+    const float *t = translation + 3 * n;
+    float u = flow[(long)n * flow_n_stride + idx];
+    float v = flow[(long)n * flow_n_stride + hw + idx];
+    if (normalized_flow) { u *= W; v *= H; }
+    const float p1x = x + 0.5f, p1y = y + 0.5f;
+    const float p2x = p1x + u, p2y = p1y + v;
+    float z;
+    if (method == 0) {
+        float P2[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            P2[0][j] = fx * R[0 + j] + cx * R[6 + j];
+            P2[1][j] = fy * R[3 + j] + cy * R[6 + j];
+            P2[2][j] = R[6 + j];
+        }
+        P2[0][3] = fx * t[0] + cx * t[2];
+        P2[1][3] = fy * t[1] + cy * t[2];
+        P2[2][3] = t[2];
+        float A[4][4];
+        A[0][0] = -fx; A[0][1] = 0;   A[0][2] = p1x - cx; A[0][3] = 0;
+        A[1][0] = 0;   A[1][1] = -fy; A[1][2] = p1y - cy; A[1][3] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            A[2][j] = p2x * P2[2][j] - P2[0][j];
+            A[3][j] = p2y * P2[2][j] - P2[1][j];
+        }
+        float X[4];
+        jacobi_null4(A, X);
+        z = X[2] / X[3];
+    } else {
+        const float rx = (p1x - cx) / fx, ry = (p1y - cy) / fy;
+        const float qx = R[0] * rx + R[1] * ry + R[2];
+        const float qy = R[3] * rx + R[4] * ry + R[5];
+        const float qz = R[6] * rx + R[7] * ry + R[8];
+        const float ax = fx * qx - (p2x - cx) * qz, bx = (p2x - cx) * t[2] - fx * t[0];
+        const float ay = fy * qy - (p2y - cy) * qz, by = (p2y - cy) * t[2] - fy * t[1];
+        z = (ax * bx + ay * by) / (ax * ax + ay * ay);
+    }
+    out[(long)n * out_n_stride + idx] = inverse_depth ? 1.0f / z : z;
+}
+
+// Backward bilinear warp.  grid: (ceil(H*W/256), N); each thread handles one pixel for all C channels.
+// The source planes of one sample are at most a few hundred KB (3 x 48 x 64 floats at level 2), i.e.
+// L1/L2 resident; the four taps of neighbouring lanes fall into the same or adjacent 128-byte lines.
+__global__ __launch_bounds__(256) void warp2d_kernel(float *__restrict__ out, long out_n_stride,
+                                                     const float *__restrict__ in, long in_n_stride,
+                                                     const float *__restrict__ disp, long disp_n_stride, int C,
+                                                     int H, int W, int normalized, int border_mode,
+                                                     float border_value)
+{
+    const int n = blockIdx.y;
+    const int hw = H * W;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw) return;
+    const int y = idx / W, x = idx - y * W;
+    float dx = disp[(long)n * disp_n_stride + idx];
+    float dy = disp[(long)n * disp_n_stride + hw + idx];
+    if (normalized) { dx *= W; dy *= H; }
+    const float sx = x + dx, sy = y + dy;
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const float a = sx - fx0, b = sy - fy0;
+    const bool finite = isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
+    const int x0 = finite ? (int)fx0 : -2, y0 = finite ? (int)fy0 : -2;
+    const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+    int xi[2] = {x0, x0 + 1}, yi[2] = {y0, y0 + 1};
+    bool okx[2], oky[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        okx[k] = xi[k] >= 0 && xi[k] < W;
+        oky[k] = yi[k] >= 0 && yi[k] < H;
+        xi[k] = min(max(xi[k], 0), W - 1);
+        yi[k] = min(max(yi[k], 0), H - 1);
+    }
+    const bool value_mode = border_mode == 1;
+    for (int c = 0; c < C; ++c) {
+        const float *p = in + (long)n * in_n_stride + (long)c * hw;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int kx = k & 1, ky = k >> 1;
+            const float g = p[yi[ky] * W + xi[kx]];
+            v[k] = (value_mode && !(finite && okx[kx] && oky[ky])) ? border_value : g;
+        }
+        float r;
+        if (finite)
+            r = w00 * v[0] + w01 * v[1] + w10 * v[2] + w11 * v[3];
+        else
+            r = value_mode ? border_value : __builtin_nanf("");
+        out[(long)n * out_n_stride + (long)c * hw + idx] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void leaky_relu_kernel(float *__restrict__ out, const float *__restrict__ in,
+                                                         long count, float leak)
+{
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 + 3 < count) {
+        float4 v = *reinterpret_cast<const float4 *>(in + i4);
+        v.x = v.x >= 0.0f ? v.x : leak * v.x;
+        v.y = v.y >= 0.0f ? v.y : leak * v.y;
+        v.z = v.z >= 0.0f ? v.z : leak * v.z;
+        v.w = v.w >= 0.0f ? v.w : leak * v.w;
+        *reinterpret_cast<float4 *>(out + i4) = v;
+    } else {
+        for (long i = i4; i < count; ++i) out[i] = in[i] >= 0.0f ? in[i] : leak * in[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void replace_nonfinite_kernel(float *__restrict__ out, const float *__restrict__ in,
+                                                                long count, float value)
+{
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 + 3 < count) {
+        float4 v = *reinterpret_cast<const float4 *>(in + i4);
+        v.x = isfinite(v.x) ? v.x : value;
+        v.y = isfinite(v.y) ? v.y : value;
+        v.z = isfinite(v.z) ? v.z : value;
+        v.w = isfinite(v.w) ? v.w : value;
+        *reinterpret_cast<float4 *>(out + i4) = v;
+    } else {
+        for (long i = i4; i < count; ++i) out[i] = isfinite(in[i]) ? in[i] : value;
+    }
+}
+
+// scale invariant gradient; block = 64 x 4 pixel tile, LDS tile with a halo of max|delta| columns/rows.
+// grid: (ceil(W/64), ceil(H/4), NC)
+#define SIG_MAX_DELTAS 8
+struct SigParams { int deltas[SIG_MAX_DELTAS]; float weights[SIG_MAX_DELTAS]; int n; };
+__global__ __launch_bounds__(256) void sig_kernel(float *__restrict__ out, const float *__restrict__ in, int H, int W,
+                                                  SigParams sp, float eps)
+{
+    const int z = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float *p = in + (long)z * H * W;
+    const float u = p[y * W + x];
+    float gx = 0.0f, gy = 0.0f;
+    for (int k = 0; k < sp.n; ++k) {
+        const int d = sp.deltas[k];
+        if (x + d >= 0 && x + d < W) {
+            const float un = p[y * W + x + d];
+            gx += sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
+        }
+        if (y + d >= 0 && y + d < H) {
+            const float un = p[(y + d) * W + x];
+            gy += sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
+        }
+    }
+    out[((long)z * 2 + 0) * H * W + y * W + x] = gx;
+    out[((long)z * 2 + 1) * H * W + y * W + x] = gy;
+}
+
+__device__ __forceinline__ void cswap(float &a, float &b)
+{
+    const float lo = fminf(a, b), hi = fmaxf(a, b);
+    // fminf/fmaxf drop NaNs; keep ordering semantics of (x>y)-(x<y) sort for finite data
+    a = lo;
+    b = hi;
+}
+// grid: (ceil(Wo/64), ceil(Ho/4), NC)
+__global__ __launch_bounds__(256) void median3x3_downsample_kernel(float *__restrict__ out, const float *__restrict__ in,
+                                                                   int H, int W, int Ho, int Wo)
+{
+    const int z = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Wo || y >= Ho) return;
+    const float *p = in + (long)z * H * W;
+    float v[9];
+    int k = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = min(max(2 * y + dy, 0), H - 1), xx = min(max(2 * x + dx, 0), W - 1);
+            v[k++] = p[yy * W + xx];
+        }
+    // median-of-9 network (Paeth)
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+    cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+    cswap(v[0], v[3]); cswap(v[5], v[8]); cswap(v[4], v[7]);
+    cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
+    cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
+    cswap(v[4], v[2]);
+    out[(long)z * Ho * Wo + y * Wo + x] = v[4];
+}
+
+// grid: (ceil(C*HW/1024), N)
+__global__ __launch_bounds__(256) void copy_channels_kernel(float *__restrict__ dst, long dst_n_stride,
+                                                            const float *__restrict__ src, long src_n_stride,
+                                                            long chw)
+{
+    const int n = blockIdx.y;
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const float *s = src + (long)n * src_n_stride;
+    float *d = dst + (long)n * dst_n_stride;
+    if (i4 + 3 < chw) {
+        *reinterpret_cast<float4 *>(d + i4) = *reinterpret_cast<const float4 *>(s + i4);
+    } else {
+        for (long i = i4; i < chw; ++i) d[i] = s[i];
+    }
+}
+
+// tf.image.resize_nearest_neighbor for integer factors (blocks_original.py:475): src = dst / factor
+// grid: (ceil(Ho*Wo/256), C, N)
+__global__ __launch_bounds__(256) void upsample_nearest_kernel(float *__restrict__ dst, long dst_n_stride,
+                                                               const float *__restrict__ src, long src_n_stride,
+                                                               int H, int W, int factor)
+{
+    const int n = blockIdx.z, c = blockIdx.y;
+    const int Ho = H * factor, Wo = W * factor;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Ho * Wo) return;
+    const int y = idx / Wo, x = idx - y * Wo;
+    dst[(long)n * dst_n_stride + (long)c * Ho * Wo + idx] =
+        src[(long)n * src_n_stride + (long)c * H * W + (y / factor) * W + (x / factor)];
+}
+
+__global__ void split_motion_kernel(const float *__restrict__ motion, float *__restrict__ rot,
+                                    float *__restrict__ trans, float *__restrict__ scale, int N)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 7) return;
+    const int n = i / 7, k = i - n * 7;
+    const float v = motion[i];
+    if (k < 3) rot[n * 3 + k] = v;
+    else if (k < 6) trans[n * 3 + k - 3] = v;
+    else scale[n] = v;
+}
+
+// ---- launchers ----------------------------------------------------------------------------------
+void launch_depth_to_flow(float *out, const float *depth, long depth_n_stride, const float *intrinsics,
+                          const float *rotation, const float *translation, int N, int H, int W,
+                          long out_n_stride, int inverse_depth, int normalize_flow, int gate, hipStream_t s)
+{
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(depth_to_flow_kernel, grid, dim3(256), 0, s, out, depth, depth_n_stride, intrinsics, rotation,
+                       translation, H, W, out_n_stride, inverse_depth, normalize_flow, gate);
+}
+
+void launch_flow_to_depth(float *out, long out_n_stride, const float *flow, long flow_n_stride,
+                          const float *intrinsics, const float *rotation, const float *translation, int N, int H,
+                          int W, int inverse_depth, int normalized_flow, int method, hipStream_t s)
+{
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(flow_to_depth_kernel, grid, dim3(256), 0, s, out, out_n_stride, flow, flow_n_stride, intrinsics,
+                       rotation, translation, H, W, inverse_depth, normalized_flow, method);
+}
+
+void launch_warp2d(float *out, long out_n_stride, const float *in, long in_n_stride, const float *disp,
+                   long disp_n_stride, int N, int C, int H, int W, int normalized, int border_mode,
+                   float border_value, hipStream_t s)
+{
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(warp2d_kernel, grid, dim3(256), 0, s, out, out_n_stride, in, in_n_stride, disp, disp_n_stride, C,
+                       H, W, normalized, border_mode, border_value);
+}
+
+void launch_leaky_relu(float *out, const float *in, long count, float leak, hipStream_t s)
+{
+    const long blocks = (count + 1023) / 1024;
+    hipLaunchKernelGGL(leaky_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, in, count, leak);
+}
+
+void launch_replace_nonfinite(float *out, const float *in, long count, float value, hipStream_t s)
+{
+    const long blocks = (count + 1023) / 1024;
+    hipLaunchKernelGGL(replace_nonfinite_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, in, count, value);
+}
+
+void launch_sig(float *out, const float *in, int NC, int H, int W, const int *deltas, const float *weights,
+                int ndeltas, float eps, hipStream_t s)
+{
+    SigParams sp;
+    sp.n = ndeltas;
+    for (int i = 0; i < ndeltas; ++i) { sp.deltas[i] = deltas[i]; sp.weights[i] = weights[i]; }
+    dim3 grid((W + 63) / 64, (H + 3) / 4, NC);
+    hipLaunchKernelGGL(sig_kernel, grid, dim3(256), 0, s, out, in, H, W, sp, eps);
+}
+
+void launch_median3x3_downsample(float *out, const float *in, int NC, int H, int W, hipStream_t s)
+{
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    dim3 grid((Wo + 63) / 64, (Ho + 3) / 4, NC);
+    hipLaunchKernelGGL(median3x3_downsample_kernel, grid, dim3(256), 0, s, out, in, H, W, Ho, Wo);
+}
+
+void launch_copy_channels(float *dst, long dst_n_stride, const float *src, long src_n_stride, int N, int C, long HW,
+                          hipStream_t s)
+{
+    const long chw = (long)C * HW;
+    dim3 grid((unsigned)((chw + 1023) / 1024), N);
+    hipLaunchKernelGGL(copy_channels_kernel, grid, dim3(256), 0, s, dst, dst_n_stride, src, src_n_stride, chw);
+}
+
+void launch_upsample_nearest(float *dst, long dst_n_stride, const float *src, long src_n_stride, int N, int C, int H,
+                             int W, int factor, hipStream_t s)
+{
+    dim3 grid((H * factor * W * factor + 255) / 256, C, N);
+    hipLaunchKernelGGL(upsample_nearest_kernel, grid, dim3(256), 0, s, dst, dst_n_stride, src, src_n_stride, H, W,
+                       factor);
+}
+
+void launch_split_motion(const float *motion, float *rot, float *trans, float *scale, int N, hipStream_t s)
+{
+    hipLaunchKernelGGL(split_motion_kernel, dim3((N * 7 + 63) / 64), dim3(64), 0, s, motion, rot, trans, scale, N);
+}
+
+}  // namespace demon

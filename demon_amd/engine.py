@@ -1,0 +1,271 @@
+"""DemonContext -- Python owner of one demon_ctx (one GPU, one HIP stream)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import DemonOutputs, LaunchRecord, c_float_p, c_int64_p
+
+
+class DemonError(ValueError):
+    """Raised for every non-zero demon_status (the reference raises ValueError / InvalidArgumentError)."""
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def _f32(a, shape=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise DemonError("%s has shape %s, expected %s" % (name, tuple(a.shape), tuple(shape)))
+    return a
+
+
+class DemonContext:
+    OUTPUT_KEYS = ("predict_flow5", "predict_conf5", "predict_flow2", "predict_conf2", "predict_depth2",
+                   "predict_normal2", "predict_rotation", "predict_translation", "predict_scale")
+
+    def __init__(self, device=0, max_batch=1, height=192, width=256):
+        self.lib = _lib.load()
+        self.h = ctypes.c_void_p()
+        rc = self.lib.demon_create(ctypes.byref(self.h), device, max_batch, height, width)
+        if rc != 0:
+            raise DemonError("demon_create failed (%d): %s" % (rc, self.lib.demon_last_error(None).decode()))
+        self.device, self.max_batch, self.H, self.W = device, max_batch, height, width
+        self.h2, self.w2, self.h5, self.w5 = height // 4, width // 4, height // 32, width // 32
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.demon_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DemonError("libdemon_hip error %d: %s" % (rc, self.lib.demon_last_error(self.h).decode()))
+
+    # ---- weights ----------------------------------------------------------------------------------------
+    def variables(self):
+        """[(tf_name, shape)] in blob order."""
+        out = []
+        name = ctypes.create_string_buffer(128)
+        dims = (ctypes.c_int64 * 4)()
+        nd = ctypes.c_int()
+        for i in range(self.lib.demon_num_variables(self.h)):
+            self._check(self.lib.demon_variable_info(self.h, i, name, 128, dims, ctypes.byref(nd)))
+            out.append((name.value.decode(), tuple(int(dims[k]) for k in range(nd.value))))
+        return out
+
+    def set_weights(self, weights):
+        """weights: dict tf_name -> array in TF layout; every variable must be present."""
+        for name, shape in self.variables():
+            if name not in weights:
+                raise DemonError("missing variable %s" % name)
+            w = _f32(weights[name], shape, name)
+            dims = (ctypes.c_int64 * len(shape))(*shape)
+            self._check(self.lib.demon_set_weight(self.h, name.encode(), _fp(w), dims, len(shape)))
+
+    def blob_size(self):
+        return int(self.lib.demon_weights_blob_size(self.h))
+
+    def set_weights_blob(self, blob):
+        blob = _f32(blob, (self.blob_size(),), "weight blob")
+        self._check(self.lib.demon_set_weights_blob(self.h, _fp(blob), blob.size))
+
+    def set_weights_blob_device(self, device_ptr, nfloats):
+        self._check(self.lib.demon_set_weights_blob_device(self.h, ctypes.c_void_p(device_ptr), nfloats))
+
+    def set_option(self, key, value):
+        self._check(self.lib.demon_set_option(self.h, key.encode(), int(value)))
+
+    # ---- networks (NCHW numpy in, dict of NCHW numpy out) -------------------------------------------------
+    def _alloc_outputs(self, n):
+        shapes = {
+            "predict_flow5": (n, 2, self.h5, self.w5), "predict_conf5": (n, 2, self.h5, self.w5),
+            "predict_flow2": (n, 2, self.h2, self.w2), "predict_conf2": (n, 2, self.h2, self.w2),
+            "predict_depth2": (n, 1, self.h2, self.w2), "predict_normal2": (n, 3, self.h2, self.w2),
+            "predict_rotation": (n, 3), "predict_translation": (n, 3), "predict_scale": (n, 1),
+        }
+        arrays = {k: np.empty(s, np.float32) for k, s in shapes.items()}
+        o = DemonOutputs(**{k: _fp(v) for k, v in arrays.items()})
+        return arrays, o
+
+    def bootstrap(self, image_pair, image2_2):
+        n = int(np.shape(image_pair)[0])
+        image_pair = _f32(image_pair, (n, 6, self.H, self.W), "image_pair")
+        image2_2 = _f32(image2_2, (n, 3, self.h2, self.w2), "image2_2")
+        arrays, o = self._alloc_outputs(n)
+        self._check(self.lib.demon_bootstrap(self.h, n, _fp(image_pair), _fp(image2_2), ctypes.byref(o)))
+        return arrays
+
+    def iterative(self, image_pair, image2_2, depth2, normal2, rotation, translation):
+        n = int(np.shape(image_pair)[0])
+        image_pair = _f32(image_pair, (n, 6, self.H, self.W), "image_pair")
+        image2_2 = _f32(image2_2, (n, 3, self.h2, self.w2), "image2_2")
+        depth2 = _f32(depth2, (n, 1, self.h2, self.w2), "depth2")
+        normal2 = _f32(normal2, (n, 3, self.h2, self.w2), "normal2")
+        rotation = _f32(rotation, (n, 3), "rotation")
+        translation = _f32(translation, (n, 3), "translation")
+        arrays, o = self._alloc_outputs(n)
+        self._check(self.lib.demon_iterative(self.h, n, _fp(image_pair), _fp(image2_2), _fp(depth2), _fp(normal2),
+                                             _fp(rotation), _fp(translation), ctypes.byref(o)))
+        return arrays
+
+    def refine(self, image1, depth2):
+        n = int(np.shape(image1)[0])
+        image1 = _f32(image1, (n, 3, self.H, self.W), "image1")
+        depth2 = _f32(depth2, (n, 1, self.h2, self.w2), "depth2")
+        d0 = np.empty((n, 1, self.H, self.W), np.float32)
+        self._check(self.lib.demon_refine(self.h, n, _fp(image1), _fp(depth2), _fp(d0)))
+        return {"predict_depth0": d0}
+
+    def full(self, image_pair, image2_2, iterations=3):
+        n = int(np.shape(image_pair)[0])
+        image_pair = _f32(image_pair, (n, 6, self.H, self.W), "image_pair")
+        image2_2 = _f32(image2_2, (n, 3, self.h2, self.w2), "image2_2")
+        arrays, o = self._alloc_outputs(n)
+        d0 = np.empty((n, 1, self.H, self.W), np.float32)
+        self._check(self.lib.demon_full(self.h, n, _fp(image_pair), _fp(image2_2), iterations, ctypes.byref(o), _fp(d0)))
+        arrays["predict_depth0"] = d0
+        return arrays
+
+    # ---- device-resident path -----------------------------------------------------------------------------
+    def upload_inputs(self, image_pair, image2_2):
+        n = int(np.shape(image_pair)[0])
+        image_pair = _f32(image_pair, (n, 6, self.H, self.W), "image_pair")
+        image2_2 = _f32(image2_2, (n, 3, self.h2, self.w2), "image2_2")
+        self._check(self.lib.demon_upload_inputs(self.h, n, _fp(image_pair), _fp(image2_2)))
+        return n
+
+    def run_full(self, n, iterations=3):
+        self._check(self.lib.demon_run_full(self.h, n, iterations))
+
+    def run_bootstrap(self, n):
+        self._check(self.lib.demon_run_bootstrap(self.h, n))
+
+    def synchronize(self):
+        self._check(self.lib.demon_synchronize(self.h))
+
+    def download_outputs(self, n, with_depth0=True):
+        arrays, o = self._alloc_outputs(n)
+        d0 = np.empty((n, 1, self.H, self.W), np.float32) if with_depth0 else None
+        self._check(self.lib.demon_download_outputs(self.h, n, ctypes.byref(o), _fp(d0) if with_depth0 else None))
+        if with_depth0:
+            arrays["predict_depth0"] = d0
+        return arrays
+
+    def time_full(self, n, iterations, steps):
+        ms = ctypes.c_float()
+        self._check(self.lib.demon_time_full(self.h, n, iterations, steps, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def profile_full(self, n, iterations=3, repeats=3):
+        cap = 1024
+        rec = (LaunchRecord * cap)()
+        cnt = ctypes.c_int()
+        self._check(self.lib.demon_profile_full(self.h, n, iterations, repeats, rec, cap, ctypes.byref(cnt)))
+        return [{"name": r.name.decode(), "kernel": r.kernel.decode(), "flops": r.flops, "bytes": r.bytes, "ms": r.ms}
+                for r in rec[:min(cnt.value, cap)]]
+
+    # ---- lmbspecialops-level ops --------------------------------------------------------------------------
+    def depth_to_flow(self, depth, intrinsics, rotation, translation, inverse_depth=False, normalize_flow=False,
+                      gate=False):
+        depth = _f32(depth)
+        n, c, h, w = depth.shape
+        intrinsics = _f32(np.broadcast_to(np.asarray(intrinsics, np.float32), (n, 4)))
+        rotation, translation = _f32(rotation, (n, 3)), _f32(translation, (n, 3))
+        out = np.empty((n, 2, h, w), np.float32)
+        self._check(self.lib.demon_op_depth_to_flow(self.h, _fp(out), _fp(depth), _fp(intrinsics), _fp(rotation),
+                                                    _fp(translation), n, h, w, int(inverse_depth), int(normalize_flow),
+                                                    int(gate)))
+        return out
+
+    def flow_to_depth(self, flow, intrinsics, rotation, translation, inverse_depth=False, normalized_flow=False,
+                      method=0):
+        flow = _f32(flow)
+        n, c, h, w = flow.shape
+        intrinsics = _f32(np.broadcast_to(np.asarray(intrinsics, np.float32), (n, 4)))
+        rotation, translation = _f32(rotation, (n, 3)), _f32(translation, (n, 3))
+        out = np.empty((n, 1, h, w), np.float32)
+        self._check(self.lib.demon_op_flow_to_depth(self.h, _fp(out), _fp(flow), _fp(intrinsics), _fp(rotation),
+                                                    _fp(translation), n, h, w, int(inverse_depth), int(normalized_flow),
+                                                    int(method)))
+        return out
+
+    def warp2d(self, inp, displacements, normalized=False, border_mode="clamp", border_value=0.0):
+        inp = _f32(inp)
+        n, c, h, w = inp.shape
+        displacements = _f32(displacements, (n, 2, h, w), "displacements")
+        out = np.empty_like(inp)
+        self._check(self.lib.demon_op_warp2d(self.h, _fp(out), _fp(inp), _fp(displacements), n, c, h, w, int(normalized),
+                                             1 if border_mode == "value" else 0, float(border_value)))
+        return out
+
+    def leaky_relu(self, x, leak=0.1):
+        x = _f32(x)
+        out = np.empty_like(x)
+        self._check(self.lib.demon_op_leaky_relu(self.h, _fp(out), _fp(x), x.size, float(leak)))
+        return out
+
+    def replace_nonfinite(self, x, value=0.0):
+        x = _f32(x)
+        out = np.empty_like(x)
+        self._check(self.lib.demon_op_replace_nonfinite(self.h, _fp(out), _fp(x), x.size, float(value)))
+        return out
+
+    def scale_invariant_gradient(self, x, deltas=(1,), weights=(1.0,), epsilon=0.001):
+        x = _f32(x)
+        n, c, h, w = x.shape
+        d = np.ascontiguousarray(deltas, np.int32)
+        wt = _f32(weights, (len(d),), "weights")
+        out = np.empty((n * c, 2, h, w), np.float32)
+        self._check(self.lib.demon_op_scale_invariant_gradient(
+            self.h, _fp(out), _fp(x), n * c, h, w, d.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(wt), len(d),
+            float(epsilon)))
+        return out
+
+    def median3x3_downsample(self, x):
+        x = _f32(x)
+        n, c, h, w = x.shape
+        out = np.empty((n, c, (h + 1) // 2, (w + 1) // 2), np.float32)
+        self._check(self.lib.demon_op_median3x3_downsample(self.h, _fp(out), _fp(x), n * c, h, w))
+        return out
+
+    # ---- single layers (TF weight layouts) ----------------------------------------------------------------
+    def conv2d(self, x, w_hwio, bias, stride=(1, 1), lrelu=False):
+        x, w_hwio, bias = _f32(x), _f32(w_hwio), _f32(bias)
+        n, cin, h, w = x.shape
+        kh, kw, ci, cout = w_hwio.shape
+        if ci != cin or bias.shape != (cout,):
+            raise DemonError("conv2d: weight / bias shape mismatch")
+        sh, sw = stride
+        ho, wo = (h + 2 * (kh // 2) - kh) // sh + 1, (w + 2 * (kw // 2) - kw) // sw + 1
+        out = np.empty((n, cout, ho, wo), np.float32)
+        self._check(self.lib.demon_op_conv2d(self.h, _fp(out), _fp(x), _fp(w_hwio), _fp(bias), n, cin, h, w, cout, kh, kw,
+                                             sh, sw, kh // 2, kw // 2, int(lrelu)))
+        return out
+
+    def deconv4x4s2(self, x, w_hwoi, bias, lrelu=False):
+        x, w_hwoi, bias = _f32(x), _f32(w_hwoi), _f32(bias)
+        n, cin, h, w = x.shape
+        if w_hwoi.shape[:2] != (4, 4) or w_hwoi.shape[3] != cin:
+            raise DemonError("deconv4x4s2: weight must be [4,4,Cout,Cin]")
+        cout = w_hwoi.shape[2]
+        out = np.empty((n, cout, 2 * h, 2 * w), np.float32)
+        self._check(self.lib.demon_op_deconv4x4s2(self.h, _fp(out), _fp(x), _fp(w_hwoi), _fp(bias), n, cin, h, w, cout,
+                                                  int(lrelu)))
+        return out
+
+    def dense(self, x, w_io, bias, lrelu=False):
+        x, w_io, bias = _f32(x), _f32(w_io), _f32(bias)
+        n, cin = x.shape
+        cout = w_io.shape[1]
+        out = np.empty((n, cout), np.float32)
+        self._check(self.lib.demon_op_dense(self.h, _fp(out), _fp(x), _fp(w_io), _fp(bias), n, cin, cout, int(lrelu)))
+        return out

@@ -1,0 +1,44 @@
+"""Process-wide context / weight registry shared by the three network classes.
+
+The reference shares one tf.Session and one set of variables between BootstrapNet, IterativeNet and
+RefinementNet (examples/example.py:70-83); here they share one DemonContext per (device, batch, size).
+"""
+import os
+
+from .engine import DemonContext, DemonError
+
+_contexts = {}
+_default_weights = None
+
+
+def set_default_weights(weights):
+    """weights: dict tf variable name -> array (TF layout).  Replaces Saver.restore (example.py:82-83)."""
+    global _default_weights
+    _default_weights = weights
+    for ctx in _contexts.values():
+        ctx.set_weights(weights)
+
+
+def default_weights():
+    return _default_weights
+
+
+def get_context(batch_size=1, height=192, width=256, device=None):
+    if device is None:
+        device = int(os.environ.get("DEMON_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    key = (device, batch_size, height, width)
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = DemonContext(device, batch_size, height, width)
+        if os.environ.get("DEMON_HIPGRAPH", "1") == "0":
+            ctx.set_option("hipgraph", 0)
+        if _default_weights is not None:
+            ctx.set_weights(_default_weights)
+        _contexts[key] = ctx
+    return ctx
+
+
+def release_all():
+    for ctx in _contexts.values():
+        ctx.close()
+    _contexts.clear()

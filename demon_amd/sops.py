@@ -1,0 +1,55 @@
+"""Mirror of the `lmbspecialops` Python API (the op set the reference calls) on
+numpy arrays, executed by the HIP kernels of libdemon_hip.so.  Argument names / order follow the
+reference's call sites (python/depthmotionnet/blocks_original.py:155-176, :336-360; v2/blocks.py:362;
+v2/losses.py:49, :78; examples/evaluation.py:173).  All image tensors are NCHW float32.
+"""
+import numpy as np
+
+from . import runtime
+
+
+def _ctx():
+    return runtime.get_context(1)
+
+
+def depth_to_flow(intrinsics, depth, rotation, translation, rotation_format="angleaxis3", inverse_depth=False,
+                  normalize_flow=False):
+    if rotation_format != "angleaxis3":
+        raise ValueError("only rotation_format='angleaxis3' is supported")
+    return _ctx().depth_to_flow(depth, intrinsics, rotation, translation, inverse_depth, normalize_flow)
+
+
+def flow_to_depth(flow, intrinsics, rotation, translation, rotation_format="angleaxis3", inverse_depth=False,
+                  normalized_flow=False):
+    if rotation_format != "angleaxis3":
+        raise ValueError("only rotation_format='angleaxis3' is supported")
+    return _ctx().flow_to_depth(flow, intrinsics, rotation, translation, inverse_depth, normalized_flow, method=0)
+
+
+def flow_to_depth2(flow, intrinsics, rotation, translation, rotation_format="angleaxis3", inverse_depth=False,
+                   normalized_flow=False):
+    if rotation_format != "angleaxis3":
+        raise ValueError("only rotation_format='angleaxis3' is supported")
+    return _ctx().flow_to_depth(flow, intrinsics, rotation, translation, inverse_depth, normalized_flow, method=1)
+
+
+def warp2d(input, displacements, normalized=False, border_mode="clamp", border_value=0.0):
+    if border_mode not in ("clamp", "value"):
+        raise ValueError("border_mode must be 'clamp' or 'value'")
+    return _ctx().warp2d(input, displacements, normalized, border_mode, border_value)
+
+
+def leaky_relu(input, leak=0.1):
+    return _ctx().leaky_relu(input, leak)
+
+
+def replace_nonfinite(input, value=0.0):
+    return _ctx().replace_nonfinite(input, value)
+
+
+def scale_invariant_gradient(input, deltas=(1,), weights=(1.0,), epsilon=0.001):
+    return _ctx().scale_invariant_gradient(input, deltas, weights, epsilon)
+
+
+def median3x3_downsample(input):
+    return _ctx().median3x3_downsample(input)

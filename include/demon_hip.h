@@ -1,0 +1,150 @@
+/*
+ * demon_hip.h -- C ABI of libdemon_hip.so, the MI355X-native (gfx950) DeMoN inference path.
+ *
+ * This is the drop-in boundary for the hot path of lmb-freiburg/demon.  The
+ * reference has no FFI of its own for this path: it builds a TF1 graph in Python and crosses into
+ * native code through tf.Session.run and the lmbspecialops custom-op library.  Each entry point
+ * below names the reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types; no exceptions cross the ABI
+ *   - every function returns 0 on success or a negative demon_status; text via demon_last_error()
+ *   - all tensors are float32, NCHW ("channels_first"), contiguous; the Python shim converts NHWC
+ *   - "host" pointers are caller-owned host memory; the context owns all device memory
+ *   - a context is bound to one device and one HIP stream and is NOT thread safe
+ *   - no device allocation happens inside any run call (hipGraph-capture safe)
+ */
+#ifndef DEMON_HIP_H
+#define DEMON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct demon_ctx demon_ctx;
+
+enum demon_status {
+    DEMON_OK = 0,
+    DEMON_ERR_INVALID = -1,     /* bad argument / shape mismatch (TF: ValueError / InvalidArgumentError) */
+    DEMON_ERR_HIP = -2,         /* a HIP runtime call failed */
+    DEMON_ERR_NOT_READY = -3,   /* weights missing */
+    DEMON_ERR_NOT_FOUND = -4    /* unknown variable / option */
+};
+
+/* Output bundle of one bootstrap / iterative evaluation; NULL members are skipped.
+ * Replaces the fetches dict of BootstrapNet.eval / IterativeNet.eval
+ * (python/depthmotionnet/networks_original.py:76-83, :182-189). Shapes for batch n at HxW input,
+ * h2 = H/4, w2 = W/4, h5 = H/32, w5 = W/32:                                                       */
+typedef struct demon_outputs {
+    float *predict_flow5;       /* [n,2,h5,w5] */
+    float *predict_conf5;       /* [n,2,h5,w5]  (attribute predict_conf5, networks_original.py:47) */
+    float *predict_flow2;       /* [n,2,h2,w2] */
+    float *predict_conf2;       /* [n,2,h2,w2] */
+    float *predict_depth2;      /* [n,1,h2,w2] */
+    float *predict_normal2;     /* [n,3,h2,w2] */
+    float *predict_rotation;    /* [n,3] angle axis */
+    float *predict_translation; /* [n,3] */
+    float *predict_scale;       /* [n,1] */
+} demon_outputs;
+
+/* ---- lifecycle -------------------------------------------------------------------------------
+ * Replaces tf.InteractiveSession + the three network constructors
+ * (examples/example.py:70-77; networks_original.py:23, :93, :204).  height/width must be multiples
+ * of 32; 192x256 is the reference's fixed size (networks_original.py:38-42).                      */
+int demon_create(demon_ctx **ctx, int device, int max_batch, int height, int width);
+int demon_destroy(demon_ctx *ctx);
+const char *demon_last_error(const demon_ctx *ctx); /* ctx may be NULL: error of a failed create */
+int demon_device(const demon_ctx *ctx);
+
+/* ---- weights ---------------------------------------------------------------------------------
+ * Replaces tf.train.Saver().restore (examples/example.py:82-83).  Variables carry their TF names
+ * and TF layouts ("netFlow1/conv1y/kernel" [9,1,6,32] HWIO; deconv [4,4,Cout,Cin]; dense [in,out];
+ * SURVEY.md appendix B); the library repacks them for the MFMA kernels.                           */
+int demon_num_variables(const demon_ctx *ctx);
+int demon_variable_info(const demon_ctx *ctx, int index, char *name, int name_cap, int64_t dims[4], int *ndim);
+int demon_set_weight(demon_ctx *ctx, const char *tf_name, const float *host, const int64_t *dims, int ndim);
+/* flat blob = all variables, TF layout, in demon_variable_info order */
+int64_t demon_weights_blob_size(const demon_ctx *ctx);
+int demon_set_weights_blob(demon_ctx *ctx, const float *host_blob, int64_t nfloats);
+/* same blob already in device memory of this context's device (e.g. after an RCCL broadcast) */
+int demon_set_weights_blob_device(demon_ctx *ctx, const void *device_blob, int64_t nfloats);
+
+/* ---- options ---------------------------------------------------------------------------------
+ * "hipgraph" 0/1 (default 1), "flow_to_depth_method" 0 = DLT/SVD, 1 = closed form (default 0)    */
+int demon_set_option(demon_ctx *ctx, const char *key, int value);
+
+/* ---- networks, host buffers in / host buffers out ------------------------------------------------
+ * demon_bootstrap  replaces BootstrapNet.eval   (networks_original.py:60-88)
+ * demon_iterative  replaces IterativeNet.eval   (networks_original.py:154-198)
+ * demon_refine     replaces RefinementNet.eval  (networks_original.py:236-255)
+ * demon_full       replaces the loop of examples/example.py:87-99 without host round trips     */
+int demon_bootstrap(demon_ctx *ctx, int n, const float *image_pair, const float *image2_2, const demon_outputs *out);
+int demon_iterative(demon_ctx *ctx, int n, const float *image_pair, const float *image2_2, const float *depth2,
+                    const float *normal2, const float *rotation, const float *translation,
+                    const demon_outputs *out);
+int demon_refine(demon_ctx *ctx, int n, const float *image1, const float *depth2, float *predict_depth0);
+int demon_full(demon_ctx *ctx, int n, const float *image_pair, const float *image2_2, int iterations,
+               const demon_outputs *out, float *predict_depth0);
+
+/* ---- device-resident path (throughput) ------------------------------------------------------------
+ * inputs stay in HBM; image1 is image_pair[:,0:3].  demon_run_full enqueues bootstrap +
+ * `iterations` x iterative + refine on the context stream (one hipGraph launch when enabled) and
+ * returns without synchronising.                                                                */
+int demon_upload_inputs(demon_ctx *ctx, int n, const float *image_pair, const float *image2_2);
+int demon_run_full(demon_ctx *ctx, int n, int iterations);
+int demon_run_bootstrap(demon_ctx *ctx, int n);
+int demon_synchronize(demon_ctx *ctx);
+int demon_download_outputs(demon_ctx *ctx, int n, const demon_outputs *out, float *predict_depth0);
+/* time `steps` back-to-back demon_run_full calls with hip events on the context stream */
+int demon_time_full(demon_ctx *ctx, int n, int iterations, int steps, float *total_ms);
+
+/* ---- per-launch profile (hip events around every kernel launch of one full pass, eager) ---------- */
+typedef struct demon_launch_record {
+    char name[64];     /* e.g. "netFlow1/conv1y" */
+    char kernel[32];   /* kernel family, e.g. "conv_mfma" */
+    double flops;      /* algorithmic 2*MAC of this launch (0 for non conv ops) */
+    double bytes;      /* algorithmic bytes read + written */
+    float ms;
+} demon_launch_record;
+int demon_profile_full(demon_ctx *ctx, int n, int iterations, int repeats, demon_launch_record *records, int cap,
+                       int *count);
+
+/* ---- lmbspecialops-level entry points (host buffers) -------------------------------------------------
+ * Replace the lmbspecialops custom ops the reference calls:
+ *   depth_to_flow            blocks_original.py:155-162 (+ gate :163-168 when gate != 0)
+ *   flow_to_depth            blocks_original.py:344-351 (method 0) / v2/blocks.py:362-378 flow_to_depth2 (method 1)
+ *   warp2d                   blocks_original.py:171-176, :336   (border_mode 0 clamp, 1 value)
+ *   leaky_relu               helpers.py:60-63
+ *   replace_nonfinite        v2/losses.py:49
+ *   scale_invariant_gradient v2/losses.py:76-79
+ *   median3x3_downsample     examples/evaluation.py:173                                              */
+int demon_op_depth_to_flow(demon_ctx *ctx, float *out, const float *depth, const float *intrinsics,
+                           const float *rotation, const float *translation, int n, int h, int w,
+                           int inverse_depth, int normalize_flow, int gate);
+int demon_op_flow_to_depth(demon_ctx *ctx, float *out, const float *flow, const float *intrinsics,
+                           const float *rotation, const float *translation, int n, int h, int w,
+                           int inverse_depth, int normalized_flow, int method);
+int demon_op_warp2d(demon_ctx *ctx, float *out, const float *input, const float *displacements, int n, int c,
+                    int h, int w, int normalized, int border_mode, float border_value);
+int demon_op_leaky_relu(demon_ctx *ctx, float *out, const float *in, int64_t count, float leak);
+int demon_op_replace_nonfinite(demon_ctx *ctx, float *out, const float *in, int64_t count, float value);
+int demon_op_scale_invariant_gradient(demon_ctx *ctx, float *out, const float *in, int nc, int h, int w,
+                                      const int *deltas, const float *weights, int ndeltas, float epsilon);
+int demon_op_median3x3_downsample(demon_ctx *ctx, float *out, const float *in, int nc, int h, int w);
+
+/* ---- layer-level entry points (host buffers; TF weight layouts) -------------------------------------
+ * Replace the tf.layers calls of helpers.py:85-94 / :128-153 (conv2d on a zero padded input),
+ * blocks_original.py:64-75 / :97-110 (conv2d_transpose k4 s2 + crop) and :390-410 (dense).        */
+int demon_op_conv2d(demon_ctx *ctx, float *out, const float *in, const float *w_hwio, const float *bias, int n,
+                    int cin, int h, int w, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int lrelu);
+int demon_op_deconv4x4s2(demon_ctx *ctx, float *out, const float *in, const float *w_hwoi, const float *bias,
+                         int n, int cin, int h, int w, int cout, int lrelu);
+int demon_op_dense(demon_ctx *ctx, float *out, const float *in, const float *w_io, const float *bias, int n,
+                   int cin, int cout, int lrelu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMON_HIP_H */

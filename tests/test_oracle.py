@@ -1,0 +1,224 @@
+"""CPU tests of the oracle itself: known answers, properties, the reference-derived golden vectors,
+and the fast (PyTorch) layers against the naive C loops."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l1, make_inputs
+from oracle import ops_ref, net_ref
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "sculpture_geometry.npz")
+K_DEMON = np.array([0.89115971, 1.18821287, 0.5, 0.5], np.float32)
+
+
+def _aa_from_R(R):
+    angle = np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
+    axis = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2 * np.sin(angle))
+    return (axis * angle).astype(np.float32)
+
+
+def test_angleaxis_matches_reference_fixture():
+    # examples/sculpture_Rt2.txt: rotation 15.68 deg, angle axis (-0.03653, 0.26291, 0.06665)
+    g = np.load(GOLDEN)
+    R = g["Rt2"][:, :3]
+    aa = _aa_from_R(R)
+    np.testing.assert_allclose(aa, [-0.03653, 0.26291, 0.06665], atol=2e-5)
+    np.testing.assert_allclose(ops_ref.angleaxis_to_rotation(aa), R, atol=1e-6)
+    # identity below 1e-6 (helpers.py:43,53-54)
+    np.testing.assert_array_equal(ops_ref.angleaxis_to_rotation(np.array([1e-7, 0, 0], np.float32)), np.eye(3))
+
+
+def test_golden_visible_mask_and_depth_ratio():
+    """depth_to_flow of the oracle reproduces what the reference's own view_tools_cython computes."""
+    g = np.load(GOLDEN)
+    depth1, depth2 = g["depth1"], g["depth2"]
+    H, W = depth1.shape
+    aa = _aa_from_R(g["Rt2"][:, :3])[None]
+    t = g["Rt2"][:, 3].astype(np.float32)[None]
+    flow = ops_ref.depth_to_flow(depth1[None, None], K_DEMON, aa, t, inverse_depth=False, normalize_flow=False)[0]
+    xs, ys = np.meshgrid(np.arange(W) + 0.5, np.arange(H) + 0.5)
+    p2x, p2y = xs + flow[0], ys + flow[1]
+    valid = np.isfinite(flow[0])
+    assert np.array_equal(valid, (depth1 > 0) & np.isfinite(depth1))
+    vis = valid & (p2x > 0) & (p2y > 0) & (p2x < W) & (p2y < H)
+    # ignore pixels that project within 1e-3 px of the image border (float rounding)
+    margin = np.minimum(np.minimum(np.abs(p2x), np.abs(p2x - W)), np.minimum(np.abs(p2y), np.abs(p2y - H)))
+    sel = ~(valid & (margin < 1e-3))
+    assert np.array_equal(vis[sel], g["visible_mask"][sel].astype(bool))
+    assert vis.mean() > 0.7
+    # depth ratios: z of the transformed point over the stored depth of view 2 at the rounded target pixel
+    R = ops_ref.angleaxis_to_rotation(aa[0]).astype(np.float64)
+    fx, fy, cx, cy = K_DEMON[0] * W, K_DEMON[1] * H, K_DEMON[2] * W, K_DEMON[3] * H
+    X = np.stack([depth1 * (xs - cx) / fx, depth1 * (ys - cy) / fy, depth1], 0).reshape(3, -1)
+    Z2 = (R @ X + t[0][:, None].astype(np.float64))[2].reshape(H, W)
+    ratios = g["depth_ratios"]
+    ok = np.isfinite(ratios) & vis
+    x2 = np.clip(np.rint(p2x[ok]).astype(int), 0, W - 1)
+    y2 = np.clip(np.rint(p2y[ok]).astype(int), 0, H - 1)
+    inside = (np.rint(p2x[ok]) < W) & (np.rint(p2y[ok]) < H)
+    mine = Z2[ok] / depth2[y2, x2]
+    good = inside & np.isfinite(mine)
+    assert good.sum() > 10000
+    # rounding of p2 can pick a neighbouring pixel of depth2 on a few edge pixels
+    close = np.abs(mine[good] - ratios[ok][good]) < 1e-3 * np.abs(ratios[ok][good])
+    assert close.mean() > 0.995
+
+
+def test_depth_to_flow_known_answers():
+    H, W = 6, 8
+    d = np.full((1, 1, H, W), 2.0, np.float32)
+    zero = np.zeros((1, 3), np.float32)
+    # no motion -> zero flow
+    f = ops_ref.depth_to_flow(d, K_DEMON, zero, zero)
+    np.testing.assert_allclose(f, 0, atol=1e-5)
+    # pure x translation: flow_x = fx*tx/z in pixels, /W when normalised; flow_y = 0
+    t = np.array([[0.5, 0, 0]], np.float32)
+    f = ops_ref.depth_to_flow(d, K_DEMON, zero, t, normalize_flow=True)
+    np.testing.assert_allclose(f[0, 0], K_DEMON[0] * 0.5 / 2.0, rtol=1e-5)
+    np.testing.assert_allclose(f[0, 1], 0, atol=1e-6)
+    # inverse depth
+    f2 = ops_ref.depth_to_flow(1 / d, K_DEMON, zero, t, inverse_depth=True, normalize_flow=True)
+    np.testing.assert_allclose(f2, f, rtol=1e-5, atol=1e-7)
+    # invalid depth -> NaN; gate turns NaN and |flow| >= 1 into 0 (blocks_original.py:163-168)
+    d[0, 0, 1, 1] = 0
+    d[0, 0, 2, 2] = -1
+    d[0, 0, 3, 3] = np.nan
+    f = ops_ref.depth_to_flow(d, K_DEMON, zero, t)
+    assert np.isnan(f[0, :, 1, 1]).all() and np.isnan(f[0, :, 2, 2]).all() and np.isnan(f[0, :, 3, 3]).all()
+    big = np.array([[10.0, 0, 0]], np.float32)
+    fg = ops_ref.depth_to_flow(d, K_DEMON, zero, big, normalize_flow=True, gate=True)
+    assert np.all(fg == 0)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_flow_depth_round_trip(method):
+    rng = np.random.default_rng(3)
+    N, H, W = 2, 48, 64
+    inv_depth = (0.2 + rng.random((N, 1, H, W))).astype(np.float32)
+    rot = (rng.standard_normal((N, 3)) * 0.1).astype(np.float32)
+    tr = rng.standard_normal((N, 3)).astype(np.float32)
+    tr /= np.linalg.norm(tr, axis=1, keepdims=True)
+    flow = ops_ref.depth_to_flow(inv_depth, K_DEMON, rot, tr, inverse_depth=True, normalize_flow=True)
+    back = ops_ref.flow_to_depth(flow, K_DEMON, rot, tr, inverse_depth=True, normalized_flow=True, method=method)
+    assert rel_l1(back, inv_depth) < 2e-3
+
+
+def test_flow_to_depth_dlt_matches_numpy_svd():
+    """the fixed-sweep Jacobi SVD of the C oracle against numpy's LAPACK SVD on inconsistent flow"""
+    rng = np.random.default_rng(4)
+    H, W = 12, 16
+    flow = (rng.standard_normal((1, 2, H, W)) * 0.05).astype(np.float32)
+    rot = np.array([[0.05, -0.1, 0.02]], np.float32)
+    tr = np.array([[0.9, 0.1, -0.3]], np.float32)
+    got = ops_ref.flow_to_depth(flow, K_DEMON, rot, tr, normalized_flow=True)[0, 0]
+    R = ops_ref.angleaxis_to_rotation(rot[0]).astype(np.float64)
+    fx, fy, cx, cy = K_DEMON[0] * W, K_DEMON[1] * H, K_DEMON[2] * W, K_DEMON[3] * H
+    Km = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]])
+    P1 = Km @ np.hstack([np.eye(3), np.zeros((3, 1))])
+    P2 = Km @ np.hstack([R, tr[0][:, None].astype(np.float64)])
+    want = np.empty((H, W))
+    for y in range(H):
+        for x in range(W):
+            p1 = np.array([x + 0.5, y + 0.5])
+            p2 = p1 + flow[0, :, y, x] * np.array([W, H])
+            A = np.stack([p1[0] * P1[2] - P1[0], p1[1] * P1[2] - P1[1], p2[0] * P2[2] - P2[0], p2[1] * P2[2] - P2[1]])
+            X = np.linalg.svd(A)[2][-1]
+            want[y, x] = X[2] / X[3]
+    assert rel_l1(got, want) < 1e-3
+
+
+def test_warp2d_known_answers():
+    rng = np.random.default_rng(5)
+    N, C, H, W = 2, 3, 10, 12
+    img = rng.random((N, C, H, W)).astype(np.float32)
+    zero = np.zeros((N, 2, H, W), np.float32)
+    np.testing.assert_array_equal(ops_ref.warp2d(img, zero, border_mode="value"), img)
+    # integer shift by (+2, -1): out(x,y) = in(x+2, y-1), zeros outside
+    d = zero.copy()
+    d[:, 0] = 2
+    d[:, 1] = -1
+    out = ops_ref.warp2d(img, d, border_mode="value")
+    want = np.zeros_like(img)
+    want[:, :, 1:, :-2] = img[:, :, :-1, 2:]
+    np.testing.assert_allclose(out, want, atol=1e-6)
+    # clamp border
+    outc = ops_ref.warp2d(img, d, border_mode="clamp")
+    np.testing.assert_allclose(outc[:, :, 0, :-2], img[:, :, 0, 2:], atol=1e-6)
+    np.testing.assert_allclose(outc[:, :, 1:, -1], img[:, :, :-1, -1], atol=1e-6)
+    # normalised half pixel shift = average of neighbours
+    d = zero.copy()
+    d[:, 0] = 0.5 / W
+    out = ops_ref.warp2d(img, d, normalized=True, border_mode="value")
+    np.testing.assert_allclose(out[..., :-1], 0.5 * (img[..., :-1] + img[..., 1:]), atol=1e-6)
+    np.testing.assert_allclose(out[..., -1], 0.5 * img[..., -1], atol=1e-6)
+    # non finite displacement -> border value
+    d = zero.copy()
+    d[0, 0, 3, 3] = np.nan
+    assert ops_ref.warp2d(img, d, border_mode="value")[0, 0, 3, 3] == 0.0
+
+
+def test_small_ops():
+    x = np.array([-2.0, -0.0, 0.0, 3.0, np.nan, np.inf, -np.inf], np.float32)
+    np.testing.assert_array_equal(ops_ref.leaky_relu(x[:4]), np.array([-0.2, -0.0, 0.0, 3.0], np.float32))
+    assert np.isnan(ops_ref.leaky_relu(x)[4])
+    np.testing.assert_array_equal(ops_ref.replace_nonfinite(x, 7.0), np.array([-2, -0.0, 0, 3, 7, 7, 7], np.float32))
+    u = np.arange(12, dtype=np.float32).reshape(1, 1, 3, 4) + 1
+    g = ops_ref.scale_invariant_gradient(u, deltas=[1], weights=[1.0], epsilon=0.0)
+    np.testing.assert_allclose(g[0, 0, 0, 0], (2 - 1) / 3.0, rtol=1e-6)
+    assert g[0, 0, 0, 3] == 0 and g[0, 1, 2, 0] == 0
+    np.testing.assert_allclose(g[0, 1, 0, 0], (5 - 1) / 6.0, rtol=1e-6)
+    m = ops_ref.median3x3_downsample(np.arange(16, dtype=np.float32).reshape(1, 1, 4, 4))
+    assert m.shape == (1, 1, 2, 2) and m[0, 0, 1, 1] == 10.0
+
+
+@pytest.mark.parametrize("cfg", [(6, 8, 9, 1, 2, 1), (8, 8, 1, 7, 1, 2), (5, 7, 3, 3, 1, 1), (4, 6, 3, 3, 2, 2), (8, 4, 5, 1, 2, 1)])
+def test_torch_conv_matches_naive_c(cfg):
+    import torch
+    import torch.nn.functional as F
+    cin, cout, kh, kw, sh, sw = cfg
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((2, cin, 12, 16)).astype(np.float32)
+    w = rng.standard_normal((kh, kw, cin, cout)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = ops_ref.conv2d_hwio(x, w, b, (sh, sw), (kh // 2, kw // 2), True)
+    xt = F.pad(torch.from_numpy(x), (kw // 2, kw // 2, kh // 2, kh // 2))
+    got = net_ref.lrelu(F.conv2d(xt, torch.from_numpy(w.transpose(3, 2, 0, 1).copy()), torch.from_numpy(b), stride=(sh, sw))).numpy()
+    assert got.shape == want.shape
+    assert rel_l1(got, want) < 1e-5
+
+
+def test_torch_deconv_and_dense_match_naive_c():
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((2, 5, 6, 8)).astype(np.float32)
+    w = rng.standard_normal((4, 4, 3, 5)).astype(np.float32)  # [kh,kw,Cout,Cin]
+    b = rng.standard_normal((3,)).astype(np.float32)
+    want = ops_ref.deconv4x4s2_crop(x, w, b, True)
+    got = net_ref.lrelu(F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(w.transpose(3, 2, 0, 1).copy()),
+                                           torch.from_numpy(b), stride=2, padding=1)).numpy()
+    assert got.shape == want.shape == (2, 3, 12, 16)
+    assert rel_l1(got, want) < 1e-5
+    xd = rng.standard_normal((3, 40)).astype(np.float32)
+    wd = rng.standard_normal((40, 7)).astype(np.float32)
+    bd = rng.standard_normal((7,)).astype(np.float32)
+    assert rel_l1(F.linear(torch.from_numpy(xd), torch.from_numpy(wd.T.copy()), torch.from_numpy(bd)).numpy(),
+                  ops_ref.dense(xd, wd, bd, False)) < 1e-5
+    up = ops_ref.resize_nearest(np.arange(6, dtype=np.float32).reshape(1, 1, 2, 3), 8, 12)
+    np.testing.assert_array_equal(up[0, 0, ::4, ::4], np.arange(6).reshape(2, 3))
+    np.testing.assert_array_equal(up[0, 0, 3, :4], 0)
+
+
+def test_full_pipeline_shapes_and_regime(synth_weights):
+    """the synthetic weights keep the oracle in a sane regime (finite outputs, gate not all-zero)"""
+    pair, img2_2 = make_inputs(1)
+    ref = net_ref.DemonRef(synth_weights)
+    r = ref.full(pair, img2_2, iterations=1)
+    assert r["predict_flow5"].shape == (1, 2, 6, 8) and r["predict_flow2"].shape == (1, 2, 48, 64)
+    assert r["predict_depth2"].shape == (1, 1, 48, 64) and r["predict_normal2"].shape == (1, 3, 48, 64)
+    assert r["predict_rotation"].shape == (1, 3) and r["predict_translation"].shape == (1, 3)
+    assert r["predict_depth0"].shape == (1, 1, 192, 256)
+    for k, v in r.items():
+        assert np.isfinite(v).all(), k
+    assert (r["predict_depth2"] > 0).mean() > 0.5
