@@ -1,0 +1,168 @@
+"""GPU parity of the three networks and the device-resident full pipeline against the CPU oracle on the
+same seeded inputs and weights, through the C ABI.  Gate: relative L1 <= 1e-3 per output tensor
+(BASELINE.json north_star); typical observed values are ~1e-6..1e-5 (summation order only)."""
+import numpy as np
+import pytest
+
+from conftest import rel_l1, make_inputs
+from oracle import net_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+KEYS = ("predict_flow5", "predict_flow2", "predict_depth2", "predict_normal2", "predict_rotation", "predict_translation")
+
+
+@pytest.fixture(scope="module")
+def ref(synth_weights):
+    return net_ref.DemonRef(synth_weights)
+
+
+def _cmp(got, want, keys, tol=TOL):
+    for k in keys:
+        assert got[k].shape == want[k].shape, k
+        assert np.isfinite(got[k]).all(), k
+        err = rel_l1(got[k], want[k])
+        assert err < tol, "%s rel L1 %.3e" % (k, err)
+
+
+def test_variable_table_matches_library(gpu_ctx):
+    from demon_amd import weights
+    lib_vars = dict(gpu_ctx.variables())
+    assert lib_vars == weights.variable_shapes()
+    assert gpu_ctx.blob_size() == 45753883
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_bootstrap(gpu_ctx, ref, n):
+    pair, img2_2 = make_inputs(n, seed=n)
+    _cmp(gpu_ctx.bootstrap(pair, img2_2), ref.bootstrap(pair, img2_2), KEYS + ("predict_conf5", "predict_conf2", "predict_scale"))
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_iterative(gpu_ctx, synth_weights, method):
+    ref = net_ref.DemonRef(synth_weights, flow_to_depth_method=method)
+    gpu_ctx.set_option("flow_to_depth_method", method)
+    try:
+        pair, img2_2 = make_inputs(2, seed=5)
+        b = ref.bootstrap(pair, img2_2)
+        args = (pair, img2_2, b["predict_depth2"], b["predict_normal2"], b["predict_rotation"], b["predict_translation"])
+        _cmp(gpu_ctx.iterative(*args), ref.iterative(*args), KEYS)
+    finally:
+        gpu_ctx.set_option("flow_to_depth_method", 0)
+
+
+def test_iterative_gate_and_nan_inputs(gpu_ctx, ref):
+    """bad camera parameters / invalid depth: the NaN gate of blocks_original.py:163-168 keeps outputs finite"""
+    pair, img2_2 = make_inputs(2, seed=6)
+    depth2 = np.full((2, 1, 48, 64), 0.5, np.float32)
+    depth2[0, 0, :10] = -1.0        # invalid inverse depth -> NaN flow -> gated to 0
+    depth2[1, 0, 5, 5] = np.nan
+    normal2 = np.zeros((2, 3, 48, 64), np.float32)
+    depth2[1, 0, 5, 5] = 0.0
+    rot = np.array([[0.0, 0.0, 0.0], [0.3, -0.2, 0.1]], np.float32)
+    tr = np.array([[5.0, 0.0, 0.0], [0.1, 0.9, -0.2]], np.float32)  # huge translation -> |flow| >= 1 -> 0
+    args = (pair, img2_2, depth2, normal2, rot, tr)
+    _cmp(gpu_ctx.iterative(*args), ref.iterative(*args), KEYS)
+
+
+def test_refine(gpu_ctx, ref):
+    pair, _ = make_inputs(2, seed=7)
+    rng = np.random.default_rng(8)
+    depth2 = (0.2 + rng.random((2, 1, 48, 64))).astype(np.float32)
+    image1 = np.ascontiguousarray(pair[:, :3])
+    _cmp(gpu_ctx.refine(image1, depth2), ref.refine(image1, depth2), ("predict_depth0",))
+
+
+def test_full_pipeline_device_resident(gpu_ctx, ref):
+    """bootstrap + 3 x iterative + refine without host round trips == the staged oracle (example.py:87-99)"""
+    pair, img2_2 = make_inputs(2, seed=9)
+    want = ref.full(pair, img2_2, iterations=3)
+    got = gpu_ctx.full(pair, img2_2, iterations=3)
+    _cmp(got, want, KEYS + ("predict_depth0",))
+    # hipGraph replay is deterministic and equals the eager launch sequence bit for bit
+    again = gpu_ctx.full(pair, img2_2, iterations=3)
+    gpu_ctx.set_option("hipgraph", 0)
+    try:
+        eager = gpu_ctx.full(pair, img2_2, iterations=3)
+    finally:
+        gpu_ctx.set_option("hipgraph", 1)
+    for k in KEYS + ("predict_depth0",):
+        np.testing.assert_array_equal(got[k], again[k])
+        np.testing.assert_array_equal(got[k], eager[k])
+    # staged host API (5 calls like example.py) == device-resident loop
+    r = gpu_ctx.bootstrap(pair, img2_2)
+    for _ in range(3):
+        r = gpu_ctx.iterative(pair, img2_2, r["predict_depth2"], r["predict_normal2"], r["predict_rotation"], r["predict_translation"])
+    d0 = gpu_ctx.refine(np.ascontiguousarray(pair[:, :3]), r["predict_depth2"])["predict_depth0"]
+    np.testing.assert_array_equal(d0, got["predict_depth0"])
+    # batch independence: pairs do not interact (no batch statistics anywhere)
+    single = gpu_ctx.full(pair[1:2], img2_2[1:2], iterations=3)
+    assert rel_l1(single["predict_depth0"], got["predict_depth0"][1:2]) < 1e-5
+
+
+def test_gate_stress_weights(gpu_ctx):
+    """un-scaled heads: flows mostly >= 1 so the gate / NaN path dominates (SURVEY 8d 'gate-stress')"""
+    from demon_amd import weights
+    w = weights.synthetic_weights(seed=2, head_scale=1.0)
+    gpu_ctx.set_weights(w)
+    try:
+        ref = net_ref.DemonRef(w)
+        pair, img2_2 = make_inputs(1, seed=10)
+        want = ref.full(pair, img2_2, iterations=1)
+        got = gpu_ctx.full(pair, img2_2, iterations=1)
+        # discontinuities (gate, floor) make per-pixel error chaotic: judge by aggregate relative L1
+        _cmp(got, want, KEYS + ("predict_depth0",), tol=5e-3)
+    finally:
+        gpu_ctx.set_weights(weights.synthetic_weights(seed=1))
+
+
+def test_reference_api_mirror_both_data_formats(synth_weights, ref):
+    """depthmotionnet.networks_original drop-in: same classes / eval signatures / keys / shapes (example.py:75-99)"""
+    import demon_amd
+    from demon_amd.networks_original import BootstrapNet, IterativeNet, RefinementNet
+    demon_amd.set_default_weights(synth_weights)
+    pair, img2_2 = make_inputs(1, seed=11)
+    results = {}
+    for df in ("channels_first", "channels_last"):
+        tr = (lambda a: a) if df == "channels_first" else (lambda a: np.ascontiguousarray(a.transpose(0, 2, 3, 1)))
+        boot, it, rf = BootstrapNet(None, df), IterativeNet(None, df), RefinementNet(None, df)
+        r = boot.eval(tr(pair), tr(img2_2))
+        assert sorted(r) == sorted(KEYS)
+        for _ in range(3):
+            r = it.eval(tr(pair), tr(img2_2), r["predict_depth2"], r["predict_normal2"], r["predict_rotation"], r["predict_translation"])
+        d0 = rf.eval(tr(pair[:, :3]), r["predict_depth2"])["predict_depth0"]
+        assert d0.shape == ((1, 1, 192, 256) if df == "channels_first" else (1, 192, 256, 1))
+        assert r["predict_flow2"].shape == ((1, 2, 48, 64) if df == "channels_first" else (1, 48, 64, 2))
+        results[df] = (d0, r)
+        with pytest.raises(ValueError):
+            boot.eval(tr(pair)[:, :-1], tr(img2_2))
+    np.testing.assert_array_equal(results["channels_first"][0], results["channels_last"][0].transpose(0, 3, 1, 2))
+    want = ref.full(pair, img2_2, 3)
+    assert rel_l1(results["channels_first"][0], want["predict_depth0"]) < TOL
+
+
+def test_other_resolution_config5_geometry(synth_weights):
+    """H x W generality needed by BASELINE config 5 (640x480), checked at a small multiple of 32"""
+    from demon_amd import DemonContext, weights
+    H, W = 96, 160
+    w = weights.synthetic_weights(seed=3, height=H, width=W)
+    ctx = DemonContext(0, 2, H, W)
+    try:
+        ctx.set_weights(w)
+        pair, img2_2 = make_inputs(2, H, W, seed=12)
+        want = net_ref.DemonRef(w).full(pair, img2_2, iterations=2)
+        got = ctx.full(pair, img2_2, iterations=2)
+        _cmp(got, want, KEYS + ("predict_depth0",))
+    finally:
+        ctx.close()
+
+
+def test_error_reporting(gpu_ctx):
+    from demon_amd import DemonError
+    pair, img2_2 = make_inputs(5)
+    with pytest.raises(DemonError):
+        gpu_ctx.bootstrap(pair, img2_2)  # batch 5 > max_batch 4
+    with pytest.raises(DemonError):
+        gpu_ctx.set_option("no_such_option", 1)
+    with pytest.raises(DemonError):
+        gpu_ctx.set_weights({"netFlow1/conv1y/kernel": np.zeros((9, 1, 6, 32), np.float32)})  # incomplete

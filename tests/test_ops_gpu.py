@@ -1,0 +1,115 @@
+"""GPU parity of the lmbspecialops-level HIP kernels against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import rel_l1
+from oracle import ops_ref
+
+pytestmark = pytest.mark.gpu
+K_DEMON = np.array([0.89115971, 1.18821287, 0.5, 0.5], np.float32)
+
+
+def _motion(rng, n):
+    rot = (rng.standard_normal((n, 3)) * 0.1).astype(np.float32)
+    tr = rng.standard_normal((n, 3)).astype(np.float32)
+    tr /= np.linalg.norm(tr, axis=1, keepdims=True)
+    return rot, tr
+
+
+@pytest.mark.parametrize("shape", [(1, 48, 64), (3, 48, 64), (2, 120, 160), (1, 5, 7)])
+@pytest.mark.parametrize("inverse,normalize,gate", [(True, True, True), (False, False, False), (True, False, False)])
+def test_depth_to_flow(gpu_ctx, shape, inverse, normalize, gate):
+    n, h, w = shape
+    rng = np.random.default_rng(10)
+    d = (0.2 + rng.random((n, 1, h, w))).astype(np.float32)
+    d.reshape(-1)[::17] = 0          # invalid depths -> NaN (-> 0 with the gate)
+    d.reshape(-1)[::29] = -1
+    d.reshape(-1)[::31] = np.nan
+    rot, tr = _motion(rng, n)
+    want = ops_ref.depth_to_flow(d, K_DEMON, rot, tr, inverse, normalize, gate)
+    got = gpu_ctx.depth_to_flow(d, K_DEMON, rot, tr, inverse, normalize, gate)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    assert rel_l1(got[m], want[m]) < 1e-4
+
+
+@pytest.mark.parametrize("method", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 48, 64), (3, 48, 64), (2, 120, 160)])
+def test_flow_to_depth(gpu_ctx, method, shape):
+    n, h, w = shape
+    rng = np.random.default_rng(11)
+    inv_depth = (0.2 + rng.random((n, 1, h, w))).astype(np.float32)
+    rot, tr = _motion(rng, n)
+    flow = ops_ref.depth_to_flow(inv_depth, K_DEMON, rot, tr, True, True)
+    flow += (rng.standard_normal(flow.shape) * 0.002).astype(np.float32)  # inconsistent flow, like a prediction
+    want = ops_ref.flow_to_depth(flow, K_DEMON, rot, tr, True, True, method)
+    got = gpu_ctx.flow_to_depth(flow, K_DEMON, rot, tr, True, True, method)
+    assert rel_l1(got, want) < 1e-3
+    # round trip property at full size: consistent flow gives the depth back
+    back = gpu_ctx.flow_to_depth(ops_ref.depth_to_flow(inv_depth, K_DEMON, rot, tr, True, True), K_DEMON, rot, tr, True, True, method)
+    assert rel_l1(back, inv_depth) < 2e-3
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 48, 64), (3, 3, 48, 64), (2, 3, 120, 160), (1, 1, 5, 7), (2, 5, 9, 130)])
+@pytest.mark.parametrize("normalized,border", [(True, "value"), (False, "clamp"), (False, "value")])
+def test_warp2d(gpu_ctx, shape, normalized, border):
+    n, c, h, w = shape
+    rng = np.random.default_rng(12)
+    img = rng.random(shape).astype(np.float32)
+    disp = rng.standard_normal((n, 2, h, w)).astype(np.float32) * (0.2 if normalized else 6.0)
+    disp[0, 0, 0, 0] = np.nan
+    disp[0, 1, h - 1, w - 1] = np.inf
+    disp[0, :, h // 2, w // 2] = 0.0
+    want = ops_ref.warp2d(img, disp, normalized, border, 0.25)
+    got = gpu_ctx.warp2d(img, disp, normalized, border, 0.25)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    assert np.abs(got[m] - want[m]).max() < 1e-4  # floor() can only flip where a,b ~ 0 or 1: continuous
+    # identity property
+    zero = np.zeros((n, 2, h, w), np.float32)
+    np.testing.assert_array_equal(gpu_ctx.warp2d(img, zero, normalized, border), img)
+
+
+def test_elementwise_and_stencils(gpu_ctx):
+    rng = np.random.default_rng(13)
+    for count in (0, 1, 3, 4, 1023, 4096 + 5):
+        x = rng.standard_normal(count).astype(np.float32)
+        if count > 3:
+            x[1], x[2], x[3] = np.nan, np.inf, -np.inf
+        got, want = gpu_ctx.leaky_relu(x, 0.1), ops_ref.leaky_relu(x, 0.1)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(gpu_ctx.replace_nonfinite(x, 2.5), ops_ref.replace_nonfinite(x, 2.5))
+    u = rng.standard_normal((2, 3, 48, 64)).astype(np.float32)
+    for deltas, weights in (([1], [1.0]), ([2], [0.5]), ([1, 2, 4, 8, 16], [1, 0.5, 0.25, 0.125, 0.0625])):
+        got = gpu_ctx.scale_invariant_gradient(u, deltas, weights, 0.01)
+        want = ops_ref.scale_invariant_gradient(u, deltas, weights, 0.01)
+        assert got.shape == want.shape == (6, 2, 48, 64)
+        assert np.abs(got - want).max() < 1e-5
+    for shape in ((2, 3, 192, 256), (1, 1, 7, 9)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        np.testing.assert_array_equal(gpu_ctx.median3x3_downsample(x), ops_ref.median3x3_downsample(x))
+    # evaluation.py:173: two median downsamples 192x256 -> 48x64
+    x = rng.random((1, 3, 192, 256)).astype(np.float32)
+    assert gpu_ctx.median3x3_downsample(gpu_ctx.median3x3_downsample(x)).shape == (1, 3, 48, 64)
+
+
+def test_sops_module_mirror(gpu_ctx, synth_weights):
+    """the lmbspecialops-style module API (keyword names of the reference call sites)"""
+    import demon_amd
+    from demon_amd import sops
+    rng = np.random.default_rng(14)
+    inv_depth = (0.2 + rng.random((1, 1, 48, 64))).astype(np.float32)
+    rot, tr = _motion(rng, 1)
+    f = sops.depth_to_flow(intrinsics=K_DEMON[None], depth=inv_depth, rotation=rot, translation=tr, inverse_depth=True,
+                           normalize_flow=True)
+    assert rel_l1(f, ops_ref.depth_to_flow(inv_depth, K_DEMON, rot, tr, True, True)) < 1e-4
+    d = sops.flow_to_depth(flow=f, intrinsics=K_DEMON[None], rotation=rot, translation=tr, normalized_flow=True, inverse_depth=True)
+    assert rel_l1(d, inv_depth) < 2e-3
+    d2 = sops.flow_to_depth2(flow=f, intrinsics=K_DEMON[None], rotation=rot, translation=tr, normalized_flow=True, inverse_depth=True)
+    assert rel_l1(d2, inv_depth) < 2e-3
+    img = rng.random((1, 3, 48, 64)).astype(np.float32)
+    wz = sops.warp2d(input=img, displacements=f, normalized=True, border_mode="value")
+    assert rel_l1(wz, ops_ref.warp2d(img, f, True, "value")) < 1e-4
+    np.testing.assert_array_equal(sops.leaky_relu(img - 0.5, leak=0.1), ops_ref.leaky_relu(img - 0.5, 0.1))
+    with pytest.raises(ValueError):
+        sops.warp2d(img, f, border_mode="mirror")
