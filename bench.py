@@ -35,11 +35,13 @@ def make_inputs(n, seed):
     return pair, img2_2
 
 
-def cpu_baseline(weights, budget_s=20.0):
+def cpu_baseline(weights, budget_s=20.0, threads=None):
     """Times the CPU oracle (full pipeline, all host cores) on a bounded sample of the same workload."""
     import torch
     from oracle import net_ref
-    cores = os.cpu_count() or 1
+    # threads actually used: torch's default intra-op pool (one per physical core visible to the process),
+    # capped at 64 -- oversubscribing the box's 256 logical CPUs made the small convs ~100x slower
+    cores = min(torch.get_num_threads(), 64) if threads is None else threads
     torch.set_num_threads(cores)
     ref = net_ref.DemonRef(weights)
     pair, img2_2 = make_inputs(4, seed=100)

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
     const int tid = threadIdx.x;
-    const int cls = blockIdx.z;
+    const int cls = blockIdx.z / a.ksplit;  // output parity class (transposed conv) ...
+    const int zs = blockIdx.z - cls * a.ksplit;  // ... and K slice (split-K for the small feature maps)
     const int m0 = blockIdx.y * BM;
     const long p0 = (long)blockIdx.x * BN;
     const long P = (long)a.N * a.Hp * a.Wp;
@@ -80,14 +81,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     float breg[BPER];
     floatx4 areg[APER];
 
+    unsigned okmask = 0;  // bit i: B element i of the prefetched K-step is inside the image
     auto load_tiles = [&](int k0) {
+        // all K-table entries of this thread's rows first (one scalar / vector load burst), then
+        // branch-free gathers: out-of-image taps read the (always valid) anchor pixel and are zeroed
+        // when they are written to LDS, so no load sits behind an exec-mask branch or an early wait
+        KEntry e[BPER];
+#pragma unroll
+        for (int i = 0; i < BPER; ++i) e[i] = ktab[k0 + bg * BPER + i];
+        okmask = 0;
 #pragma unroll
         for (int i = 0; i < BPER; ++i) {
-            const KEntry e = ktab[k0 + bg + i * BROWS];
-            const int dy = e.dydx >> 16;
-            const int dx = (int)(short)(e.dydx & 0xffff);
-            const bool ok = (unsigned)(iy0 + dy) < (unsigned)a.H && (unsigned)(ix0 + dx) < (unsigned)a.W;
-            breg[i] = ok ? inb[e.delta] : 0.0f;
+            const int dy = e[i].dydx >> 16;
+            const int dx = (int)(short)(e[i].dydx & 0xffff);
+            const bool ok = ((unsigned)(iy0 + dy) < (unsigned)a.H) & ((unsigned)(ix0 + dx) < (unsigned)a.W);
+            okmask |= (ok ? 1u : 0u) << i;
+            breg[i] = inb[ok ? e[i].delta : 0];
         }
 #pragma unroll
         for (int i = 0; i < APER; ++i) {
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < BPER; ++i) Bs[buf][bg + i * BROWS][bj] = breg[i];
+        for (int i = 0; i < BPER; ++i) Bs[buf][bg * BPER + i][bj] = ((okmask >> i) & 1u) ? breg[i] : 0.0f;
 #pragma unroll
         for (int i = 0; i < APER; ++i) {
             const int row = arow + i * AROWS;
@@ -118,33 +127,60 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nsteps = a.Kpad / BK;
-    load_tiles(0);
-    store_tiles(0);
+    const int total_steps = a.Kpad / BK;
+    const int per_slice = (total_steps + a.ksplit - 1) / a.ksplit;
+    const int s_begin = zs * per_slice;
+    const int nsteps = min(total_steps, s_begin + per_slice) - s_begin;  // may be <= 0 for a trailing slice
+    if (nsteps > 0) {
+        load_tiles(s_begin * BK);
+        store_tiles(0);
+    }
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) load_tiles((s + 1) * BK);
+        if (s + 1 < nsteps) load_tiles((s_begin + s + 1) * BK);
+        {
+            // all fragments of the K-step first, then the MFMAs back to back
+            float av[BK / 2][TM], bv[BK / 2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int k = 2 * kk + lhi;
-            float av[TM], bv[TN];
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int k = 2 * kk + lhi;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[buf][k][(wm * TM + i) * 32 + l31];
+                for (int i = 0; i < TM; ++i) av[kk][i] = As[buf][k][(wm * TM + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][k][(wn * TN + j) * 32 + l31];
+                for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[buf][k][(wn * TN + j) * 32 + l31];
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][i], bv[kk][j], acc[i][j], 0, 0, 0);
         }
         if (s + 1 < nsteps) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
+    if (a.ksplit > 1) {
+        // split-K: raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
+        float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long p = p0 + (wn * TN + j) * 32 + l31;
+            if (p >= P) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    ws[(long)co * P + p] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     // ---- epilogue: bias, leaky relu, optional per-sample scale of channel 0, coalesced NCHW store
-    const int pyc = (gridDim.z > 1) ? (cls >> 1) : 0, pxc = (gridDim.z > 1) ? (cls & 1) : 0;
+    const int pyc = cls >> 1, pxc = cls & 1;  // cls = 0 for plain convs
     const long plane = (long)a.Ho * a.Wo;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -172,41 +208,86 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     }
 }
 
-struct TileInfo { int bm, bn, threads; };
+// sums the split-K slices, then the same epilogue as the fused path.  grid: (ceil(P/256), Cout, ncls)
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a)
+{
+    const long P = (long)a.N * a.Hp * a.Wp;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int co = blockIdx.y, cls = blockIdx.z;
+    const float *__restrict__ ws = a.ws + (((long)cls * a.ksplit) * a.Mpad + co) * P + p;
+    float v = 0.0f;
+    for (int z = 0; z < a.ksplit; ++z) v += ws[(long)z * a.Mpad * P];
+    v += a.bias[co];
+    if (a.act) v = v >= 0.0f ? v : 0.1f * v;
+    const int x = (int)(p % a.Wp);
+    const long t = p / a.Wp;
+    const int y = (int)(t % a.Hp);
+    const int n = (int)(t / a.Hp);
+    if (co == 0 && a.scale) v *= a.scale[n];
+    a.out[(long)n * a.out_n_stride + (long)co * a.Ho * a.Wo + (long)(y * a.osy + (cls >> 1)) * a.Wo + (x * a.osx + (cls & 1))] = v;
+}
+
+struct TileInfo { int bm, bn, threads; float eff; };
 static const TileInfo kTiles[TILE_COUNT] = {
-    {128, 128, 256}, {64, 128, 256}, {32, 128, 256}, {64, 64, 256}, {32, 64, 128}, {32, 32, 64},
+    {128, 128, 256, 1.00f}, {64, 128, 256, 0.95f}, {32, 128, 256, 0.80f}, {64, 64, 256, 0.85f},
+    {32, 64, 128, 0.65f},   {32, 32, 64, 0.45f},   {128, 32, 256, 0.80f}, {64, 32, 128, 0.65f},
 };
 
-int choose_conv_tile(int Mpad, long pixels, int nclasses)
+// Picks the tile shape and the split-K factor.  Large tiles reuse operands best; the deep layers of the
+// encoder (6x8 / 12x16 maps, K up to 4608) and the dense layers have too few output tiles to fill 256
+// CUs, so their K loop is cut into slices until about two workgroups per CU exist.
+ConvPlan choose_conv_plan(int Mpad, long pixels, int nclasses, int Kpad, long ws_floats)
 {
-    // largest tile (most operand reuse) that still yields >= 1.5 workgroups per CU; otherwise the
-    // candidate with the most workgroups (small feature maps: 6x8 and 12x16 levels, dense layers)
-    static const int order[TILE_COUNT] = {TILE_128x128, TILE_64x128, TILE_64x64, TILE_32x128, TILE_32x64, TILE_32x32};
-    int best = -1;
-    long best_wgs = -1;
-    for (int oi = 0; oi < TILE_COUNT; ++oi) {
-        const int t = order[oi];
-        if (Mpad % kTiles[t].bm) continue;
-        const long wgs = (long)(Mpad / kTiles[t].bm) * ((pixels + kTiles[t].bn - 1) / kTiles[t].bn) * nclasses;
-        if (wgs >= 384) return t;
-        if (wgs > best_wgs) { best_wgs = wgs; best = t; }
+    const int nsteps = Kpad / 16;
+    ConvPlan best{TILE_32x32, 1};
+    float best_score = -1.0f;
+    for (int t = 0; t < TILE_COUNT; ++t) {
+        const TileInfo &ti = kTiles[t];
+        if (Mpad % ti.bm) continue;
+        if (ti.bn > 32 && pixels * 2 <= ti.bn) continue;  // more than half of the pixel tile would be padding
+        const long wgs = (long)(Mpad / ti.bm) * ((pixels + ti.bn - 1) / ti.bn) * nclasses;
+        int split = 1;
+        if (wgs < 384) {
+            split = (int)((512 + wgs - 1) / wgs);
+            const int smax = nsteps / 4 > 1 ? nsteps / 4 : 1;
+            if (split > smax) split = smax;
+            while (split > 1 && (long)nclasses * split * Mpad * pixels > ws_floats) --split;
+        }
+        float fill = (float)(wgs * split) / 512.0f;
+        if (fill > 1.0f) fill = 1.0f;
+        const float score = ti.eff * fill / (1.0f + 0.12f * (split - 1));
+        if (score > best_score) { best_score = score; best = ConvPlan{t, split}; }
     }
     return best;
 }
 
-void launch_conv_mfma(const ConvArgs &a, int tile, int nclasses, hipStream_t stream)
+template <int BM, int BN, int WM, int WN>
+static void launch_tile(const ConvArgs &a, dim3 grid, hipStream_t stream)
 {
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), 0, stream, a);
+}
+
+void launch_conv_mfma(const ConvArgs &a_in, ConvPlan plan, int nclasses, hipStream_t stream)
+{
+    ConvArgs a = a_in;
+    a.ksplit = plan.ksplit;
     const long P = (long)a.N * a.Hp * a.Wp;
-    const TileInfo ti = kTiles[tile];
-    dim3 grid((unsigned)((P + ti.bn - 1) / ti.bn), (unsigned)(a.Mpad / ti.bm), (unsigned)nclasses);
-    dim3 block(ti.threads);
-    switch (tile) {
-        case TILE_128x128: hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 2, 2>), grid, block, 0, stream, a); break;
-        case TILE_64x128:  hipLaunchKernelGGL((conv_mfma_kernel<64, 128, 2, 2>), grid, block, 0, stream, a); break;
-        case TILE_32x128:  hipLaunchKernelGGL((conv_mfma_kernel<32, 128, 1, 4>), grid, block, 0, stream, a); break;
-        case TILE_64x64:   hipLaunchKernelGGL((conv_mfma_kernel<64, 64, 2, 2>), grid, block, 0, stream, a); break;
-        case TILE_32x64:   hipLaunchKernelGGL((conv_mfma_kernel<32, 64, 1, 2>), grid, block, 0, stream, a); break;
-        default:           hipLaunchKernelGGL((conv_mfma_kernel<32, 32, 1, 1>), grid, block, 0, stream, a); break;
+    const TileInfo ti = kTiles[plan.tile];
+    dim3 grid((unsigned)((P + ti.bn - 1) / ti.bn), (unsigned)(a.Mpad / ti.bm), (unsigned)(nclasses * plan.ksplit));
+    switch (plan.tile) {
+        case TILE_128x128: launch_tile<128, 128, 2, 2>(a, grid, stream); break;
+        case TILE_64x128:  launch_tile<64, 128, 2, 2>(a, grid, stream); break;
+        case TILE_32x128:  launch_tile<32, 128, 1, 4>(a, grid, stream); break;
+        case TILE_64x64:   launch_tile<64, 64, 2, 2>(a, grid, stream); break;
+        case TILE_32x64:   launch_tile<32, 64, 1, 2>(a, grid, stream); break;
+        case TILE_128x32:  launch_tile<128, 32, 4, 1>(a, grid, stream); break;
+        case TILE_64x32:   launch_tile<64, 32, 2, 1>(a, grid, stream); break;
+        default:           launch_tile<32, 32, 1, 1>(a, grid, stream); break;
+    }
+    if (plan.ksplit > 1) {
+        dim3 rgrid((unsigned)((P + 255) / 256), (unsigned)a.Cout, (unsigned)nclasses);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, rgrid, dim3(256), 0, stream, a);
     }
 }
 

@@ -70,6 +70,7 @@ struct demon_ctx {
     // io / state
     View image_pair, image2_2, flowconf5, flowconf2, depth2, normal2, depth0;
     float *d_rot = nullptr, *d_trans = nullptr, *d_scale = nullptr, *d_motion = nullptr, *d_intrinsics = nullptr;
+    float *d_ws = nullptr;  // split-K workspace
 };
 
 namespace {
@@ -212,9 +213,12 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
     return DEMON_OK;
 }
 
-void run_layer(const Layer *L, int n, hipStream_t s)
+constexpr long kSplitKWorkspaceFloats = 16l << 20;  // 64 MiB
+
+void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
 {
     ConvArgs a;
+    a.ws = ws;
     a.in = L->in.ptr();
     a.out = L->out.ptr();
     a.wp = L->d_wp;
@@ -239,7 +243,7 @@ void run_layer(const Layer *L, int n, hipStream_t s)
         a.Hp = L->out.H; a.Wp = L->out.W; a.sy = L->sh; a.sx = L->sw; a.osy = 1; a.osx = 1;
     }
     const long P = (long)n * a.Hp * a.Wp;
-    launch_conv_mfma(a, choose_conv_tile(L->Mpad, P, L->ncls), L->ncls, s);
+    launch_conv_mfma(a, choose_conv_plan(L->Mpad, P, L->ncls, L->Kpad, ws ? kSplitKWorkspaceFloats : 0), L->ncls, s);
 }
 
 // ---- topology builder ---------------------------------------------------------------------------------
@@ -274,7 +278,8 @@ struct Builder {
         st.flops_per_sample = 2.0 * out.C * kreal * pix;
         st.bytes_per_sample = 4.0 * ((double)in.C * in.H * in.W + (double)out.C * out.H * out.W);
         st.bytes_fixed = 4.0 * ((double)p->K * p->ncls * out.C + out.C);
-        st.fn = [p](int n, hipStream_t s) { run_layer(p, n, s); };
+        float *ws = c->d_ws;
+        st.fn = [p, ws](int n, hipStream_t s) { run_layer(p, n, s, ws); };
         steps->push_back(st);
         return p;
     }
@@ -612,7 +617,8 @@ int demon_create(demon_ctx **out, int device, int max_batch, int height, int wid
     p->d_scale = dev_alloc(p, sizeof(float) * max_batch);
     p->d_motion = dev_alloc(p, sizeof(float) * 7 * max_batch);
     p->d_intrinsics = dev_alloc(p, sizeof(float) * 4 * max_batch);
-    if (!p->d_rot || !p->d_trans || !p->d_scale || !p->d_motion || !p->d_intrinsics) {
+    p->d_ws = dev_alloc(p, sizeof(float) * kSplitKWorkspaceFloats);
+    if (!p->d_ws || !p->d_rot || !p->d_trans || !p->d_scale || !p->d_motion || !p->d_intrinsics) {
         demon_destroy(c.release());
         return fail(nullptr, DEMON_ERR_HIP, "device allocation failed");
     }
@@ -1008,7 +1014,7 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
     if (!rc && hipMemcpy(L.in.base, in, sizeof(float) * (size_t)n * cin * h * wd, hipMemcpyHostToDevice) != hipSuccess)
         rc = fail(c, DEMON_ERR_HIP, "input upload failed");
     if (!rc) {
-        run_layer(&L, n, c->stream);
+        run_layer(&L, n, c->stream, c->d_ws);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
             hipMemcpy(out, L.out.base, sizeof(float) * (size_t)n * cout * ho * wo, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(c, DEMON_ERR_HIP, "layer execution failed");

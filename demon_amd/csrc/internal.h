@@ -55,12 +55,15 @@ struct ConvArgs {
     int osy, osx;       // output placement: oy = y*osy + py, ox = x*osx + px
     int act;            // 1 = leaky relu 0.1
     long cls_w_stride;  // Kpad*Mpad
+    float *ws;          // split-K workspace [cls][slice][Mpad][P]
+    int ksplit;         // number of K slices (1 = fused epilogue)
 };
 
-enum ConvTile { TILE_128x128 = 0, TILE_64x128, TILE_32x128, TILE_64x64, TILE_32x64, TILE_32x32, TILE_COUNT };
+enum ConvTile { TILE_128x128 = 0, TILE_64x128, TILE_32x128, TILE_64x64, TILE_32x64, TILE_32x32, TILE_128x32, TILE_64x32, TILE_COUNT };
+struct ConvPlan { int tile; int ksplit; };
 
-void launch_conv_mfma(const ConvArgs &a, int tile, int nclasses, hipStream_t stream);
-int choose_conv_tile(int Mpad, long pixels, int nclasses);
+void launch_conv_mfma(const ConvArgs &a, ConvPlan plan, int nclasses, hipStream_t stream);
+ConvPlan choose_conv_plan(int Mpad, long pixels, int nclasses, int Kpad, long ws_floats);
 
 // ---- op launchers (ops.hip) --------------------------------------------------------------------
 void launch_depth_to_flow(float *out, const float *depth, long depth_n_stride, const float *intrinsics,
