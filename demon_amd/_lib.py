@@ -63,6 +63,7 @@ SIGNATURES = {
     "demon_op_conv2d": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 12),
     "demon_op_deconv4x4s2": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 6),
     "demon_op_dense": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 4),
+    "demon_bench_layer": (_I, [_P] + [_I] * 13 + [c_float_p, ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None

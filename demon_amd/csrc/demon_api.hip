@@ -35,6 +35,7 @@ struct Layer {
     KEntry *d_ktab = nullptr;
     bool have_kernel = false, have_bias = false;
     std::vector<int64_t> kernel_dims;  // TF layout
+    int force_tile = -1, force_split = 0;  // tuning override (demon_bench_layer)
 };
 
 struct Step {
@@ -243,7 +244,10 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
         a.Hp = L->out.H; a.Wp = L->out.W; a.sy = L->sh; a.sx = L->sw; a.osy = 1; a.osx = 1;
     }
     const long P = (long)n * a.Hp * a.Wp;
-    launch_conv_mfma(a, choose_conv_plan(L->Mpad, P, L->ncls, L->Kpad, ws ? kSplitKWorkspaceFloats : 0), L->ncls, s);
+    ConvPlan plan = choose_conv_plan(L->Mpad, P, L->ncls, L->Kpad, ws ? kSplitKWorkspaceFloats : 0);
+    if (L->force_tile >= 0) plan.tile = L->force_tile;
+    if (L->force_split > 0) plan.ksplit = L->force_split;
+    launch_conv_mfma(a, plan, L->ncls, s);
 }
 
 // ---- topology builder ---------------------------------------------------------------------------------
@@ -1018,6 +1022,65 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess ||
             hipMemcpy(out, L.out.base, sizeof(float) * (size_t)n * cout * ho * wo, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(c, DEMON_ERR_HIP, "layer execution failed");
+    }
+    for (void *p : scratch.allocations) hipFree(p);
+    return rc;
+}
+
+// Times one contraction layer on device-resident random data (tuning / roofline diagnostics).
+// kind: 0 conv (kh x kw, stride sh x sw, pad k/2), 1 transposed conv k4 s2, 2 dense.  tile < 0 / ksplit <= 0: automatic plan.
+int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw,
+                      int tile, int ksplit, int iters, float *avg_ms, double *flops)
+{
+    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || tile >= TILE_COUNT) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    hipSetDevice(c->device);
+    demon_ctx scratch;
+    scratch.device = c->device;
+    scratch.max_batch = n;
+    Layer L;
+    L.kind = kind == 0 ? Layer::CONV : (kind == 1 ? Layer::DECONV : Layer::DENSE);
+    if (kind == 1) { kh = kw = 4; sh = sw = 2; }
+    if (kind == 2) { kh = kw = sh = sw = 1; h = wd = 1; }
+    L.Cin = cin; L.Cout = cout; L.kh = kh; L.kw = kw; L.sh = sh; L.sw = sw; L.ph = kh / 2; L.pw = kw / 2; L.act = 1;
+    int ho, wo;
+    if (kind == 1) { ho = 2 * h; wo = 2 * wd; }
+    else if (kind == 2) { ho = wo = 1; }
+    else { ho = (h + 2 * L.ph - kh) / sh + 1; wo = (wd + 2 * L.pw - kw) / sw + 1; }
+    L.in = buffer(&scratch, "in", cin, h, wd);
+    L.out = buffer(&scratch, "out", cout, ho, wo);
+    int rc = DEMON_OK;
+    if (!L.in.base || !L.out.base || !plan_layer(&scratch, &L)) rc = fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    if (!rc) {
+        // deterministic pseudo-random fill (full-range values: zero-filled operands would clock higher)
+        const size_t nin = (size_t)n * cin * h * wd, nw = (size_t)L.ncls * L.Kpad * L.Mpad;
+        std::vector<float> hin(nin), hw(nw);
+        unsigned st = 12345u;
+        auto rnd = [&st]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+        for (auto &v : hin) v = rnd();
+        for (auto &v : hw) v = rnd() * 0.05f;
+        if (hipMemcpy(L.in.base, hin.data(), nin * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(L.d_wp, hw.data(), nw * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(c, DEMON_ERR_HIP, "upload failed");
+    }
+    if (!rc) {
+        L.force_tile = tile;
+        L.force_split = ksplit;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int i = 0; i < 3; ++i) run_layer(&L, n, c->stream, c->d_ws);
+        hipEventRecord(e0, c->stream);
+        for (int i = 0; i < iters; ++i) run_layer(&L, n, c->stream, c->d_ws);
+        hipEventRecord(e1, c->stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(c, DEMON_ERR_HIP, "layer execution failed");
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        *avg_ms = ms / iters;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        const double pix = kind == 1 ? 4.0 * h * wd : (double)ho * wo;
+        const double kreal = kind == 1 ? 4.0 * cin : (double)L.K;
+        if (flops) *flops = 2.0 * cout * kreal * pix * n;
     }
     for (void *p : scratch.allocations) hipFree(p);
     return rc;

@@ -269,3 +269,13 @@ class DemonContext:
         out = np.empty((n, cout), np.float32)
         self._check(self.lib.demon_op_dense(self.h, _fp(out), _fp(x), _fp(w_io), _fp(bias), n, cin, cout, int(lrelu)))
         return out
+
+    # ---- tuning / diagnostics -----------------------------------------------------------------------------
+    def bench_layer(self, kind, n, cin, h, w, cout, kh=1, kw=1, sh=1, sw=1, tile=-1, ksplit=0, iters=20):
+        """kind: 'conv' | 'deconv' | 'dense'.  Returns (avg_ms, TFLOP/s)."""
+        k = {"conv": 0, "deconv": 1, "dense": 2}[kind]
+        ms = ctypes.c_float()
+        fl = ctypes.c_double()
+        self._check(self.lib.demon_bench_layer(self.h, k, n, cin, h, w, cout, kh, kw, sh, sw, tile, ksplit, iters,
+                                               ctypes.byref(ms), ctypes.byref(fl)))
+        return float(ms.value), fl.value / (ms.value * 1e-3) / 1e12

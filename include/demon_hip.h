@@ -144,6 +144,12 @@ int demon_op_deconv4x4s2(demon_ctx *ctx, float *out, const float *in, const floa
 int demon_op_dense(demon_ctx *ctx, float *out, const float *in, const float *w_io, const float *bias, int n,
                    int cin, int cout, int lrelu);
 
+/* ---- tuning / diagnostics ----------------------------------------------------------------------------
+ * Times one contraction layer (kind 0 conv, 1 transposed conv k4 s2, 2 dense) on device-resident random
+ * data with hip events; tile < 0 / ksplit <= 0 select the automatic plan.  Not on the reference's path. */
+int demon_bench_layer(demon_ctx *ctx, int kind, int n, int cin, int h, int w, int cout, int kh, int kw, int sh,
+                      int sw, int tile, int ksplit, int iters, float *avg_ms, double *flops);
+
 #ifdef __cplusplus
 }
 #endif
