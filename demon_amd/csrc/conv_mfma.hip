@@ -20,6 +20,8 @@
 // of a double-buffered LDS tile, one barrier per K-step.  A 64-cycle MFMA needs one 4-byte LDS read
 // per operand per lane, so LDS bandwidth is never the limit; the tile shapes below only trade
 // operand reuse (global -> LDS traffic) against the number of workgroups for the small feature maps.
+#include <type_traits>
+
 #include "internal.h"
 
 namespace demon {
@@ -80,30 +82,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
 
     float breg[BPER];
     floatx4 areg[APER];
+    KEntry kentA[BPER], kentB[BPER];  // K-table entries, two K-steps in flight (even / odd step)
+    unsigned okmask = 0;              // bit i: B element i of the prefetched K-step is inside the image
 
-    unsigned okmask = 0;  // bit i: B element i of the prefetched K-step is inside the image
-    auto load_tiles = [&](int k0) {
-        // all K-table entries of this thread's rows first (one scalar / vector load burst), then
-        // branch-free gathers: out-of-image taps read the (always valid) anchor pixel and are zeroed
-        // when they are written to LDS, so no load sits behind an exec-mask branch or an early wait
-        KEntry e[BPER];
+    // The prefetch of K-step s+1 is cut into per-element pieces that are issued in the shadow of the
+    // MFMA groups of K-step s (a 64-cycle fp32 MFMA hides ~10 other instructions of the same wave):
+    //   load_ktab   one scalar (vector for 32-pixel tiles) burst with this thread's BPER table entries.
+    //               Every K-step touches a fresh 128-byte piece of the table, i.e. a scalar-cache miss of
+    //               ~1000 cycles that the lock-stepped waves of a SIMD would all sit out together, so the
+    //               table runs TWO steps ahead of the MFMAs (one step ahead of the gathers that use it).
+    //   gather_one  branch-free gather: out-of-image taps read the (always valid) anchor pixel and are
+    //               zeroed when written to LDS, so no load sits behind an exec-mask branch
+    auto load_ktab = [&](KEntry (&kent)[BPER], int step) {
+        step = min(step, a.Kpad / BK - 1);  // the run-ahead may point past the table: re-read the last step
 #pragma unroll
-        for (int i = 0; i < BPER; ++i) e[i] = ktab[k0 + bg * BPER + i];
-        okmask = 0;
-#pragma unroll
-        for (int i = 0; i < BPER; ++i) {
-            const int dy = e[i].dydx >> 16;
-            const int dx = (int)(short)(e[i].dydx & 0xffff);
-            const bool ok = ((unsigned)(iy0 + dy) < (unsigned)a.H) & ((unsigned)(ix0 + dx) < (unsigned)a.W);
-            okmask |= (ok ? 1u : 0u) << i;
-            breg[i] = inb[ok ? e[i].delta : 0];
-        }
-#pragma unroll
-        for (int i = 0; i < APER; ++i) {
-            const int row = arow + i * AROWS;
-            if (AROWS * APER == BK || row < BK)
-                areg[i] = *reinterpret_cast<const floatx4 *>(wp + (long)(k0 + row) * a.Mpad + m0 + ac4 * 4);
-        }
+        for (int i = 0; i < BPER; ++i) kent[i] = ktab[step * BK + bg * BPER + i];
+    };
+    auto gather_one = [&](const KEntry (&kent)[BPER], int i) {
+        const int dy = kent[i].dydx >> 16;
+        const int dx = (int)(short)(kent[i].dydx & 0xffff);
+        const bool ok = ((unsigned)(iy0 + dy) < (unsigned)a.H) & ((unsigned)(ix0 + dx) < (unsigned)a.W);
+        okmask |= (ok ? 1u : 0u) << i;
+        breg[i] = inb[ok ? kent[i].delta : 0];
+    };
+    auto load_a_one = [&](int i, int step) {
+        const int row = arow + i * AROWS;
+        if (AROWS * APER == BK || row < BK)
+            areg[i] = *reinterpret_cast<const floatx4 *>(wp + (long)(step * BK + row) * a.Mpad + m0 + ac4 * 4);
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
@@ -127,40 +132,86 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // One K-step on LDS buffer `buf`: the fragments of the whole step, then 8 MFMA groups.  With PREFETCH the
+    // global loads of step `next` (table entries in kent_use) and the table read of step next+1 (into
+    // kent_load) are pinned between the groups; sched_barrier keeps that order.
+    constexpr int NG = BK / 2;
+    auto kstep = [&](int buf, int next, const KEntry (&kent_use)[BPER], KEntry (&kent_load)[BPER], auto prefetch) {
+        constexpr bool PREFETCH = decltype(prefetch)::value;
+        float av[NG][TM], bv[NG][TN];
+#pragma unroll
+        for (int kk = 0; kk < NG; ++kk) {
+            const int k = 2 * kk + lhi;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[kk][i] = As[buf][k][(wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[buf][k][(wn * TN + j) * 32 + l31];
+        }
+        if (PREFETCH) {
+            okmask = 0;
+            // all LDS reads back before the first MFMA (~150 cycles, once per step): the scalar table read
+            // issued below shares lgkmcnt with them and returns out of order, so any later LDS wait would
+            // turn into lgkmcnt(0) and sit out the table's cache miss
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
+            if (PREFETCH) {
+                // the gathers go behind the FIRST half of the groups so that the last one still has ~1000
+                // cycles of MFMA work to land before store_tiles waits for it (lock-stepped waves do not
+                // cover each other's waits)
+                constexpr int GH = NG / 2;
+                if (g < GH) {
+#pragma unroll
+                    for (int i = g * BPER / GH; i < (g + 1) * BPER / GH; ++i) gather_one(kent_use, i);
+                }
+                if (g < APER) load_a_one(g, next);
+                // table entries of step next+1 into the register set that step next-1 used.  Issued here,
+                // behind this step's LDS reads, so that no lgkmcnt(0) wait of this step covers the miss.
+                if (g == GH) load_ktab(kent_load, next + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     const int total_steps = a.Kpad / BK;
     const int per_slice = (total_steps + a.ksplit - 1) / a.ksplit;
     const int s_begin = zs * per_slice;
     const int nsteps = min(total_steps, s_begin + per_slice) - s_begin;  // may be <= 0 for a trailing slice
     if (nsteps > 0) {
-        load_tiles(s_begin * BK);
+        load_ktab(kentA, s_begin);
+        load_ktab(kentB, s_begin + 1);
+#pragma unroll
+        for (int i = 0; i < BPER; ++i) gather_one(kentA, i);
+#pragma unroll
+        for (int i = 0; i < APER; ++i) load_a_one(i, s_begin);
         store_tiles(0);
     }
     __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nsteps) load_tiles((s_begin + s + 1) * BK);
-        {
-            // all fragments of the K-step first, then the MFMAs back to back
-            float av[BK / 2][TM], bv[BK / 2][TN];
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                const int k = 2 * kk + lhi;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) av[kk][i] = As[buf][k][(wm * TM + i) * 32 + l31];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[buf][k][(wn * TN + j) * 32 + l31];
-            }
-#pragma unroll
-            for (int kk = 0; kk < BK / 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][i], bv[kk][j], acc[i][j], 0, 0, 0);
-        }
-        if (s + 1 < nsteps) store_tiles(buf ^ 1);
+    // steps in pairs so that the table double buffer is indexed statically: during an even step s the gathers
+    // of step s+1 read kentB while kentA is refilled for step s+2, and vice versa during odd steps
+    int s = 0;
+    for (; s + 2 < nsteps; s += 2) {
+        kstep(0, s_begin + s + 1, kentB, kentA, std::true_type{});
+        store_tiles(1);
+        __syncthreads();
+        kstep(1, s_begin + s + 2, kentA, kentB, std::true_type{});
+        store_tiles(0);
         __syncthreads();
     }
+    if (s + 1 < nsteps) {
+        kstep(0, s_begin + s + 1, kentB, kentA, std::true_type{});
+        store_tiles(1);
+        __syncthreads();
+        ++s;
+    }
+    if (nsteps > 0) kstep(s & 1, 0, kentA, kentB, std::false_type{});
 
     if (a.ksplit > 1) {
         // split-K: raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes

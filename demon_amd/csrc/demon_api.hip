@@ -7,6 +7,7 @@
 // host round trip happens between the stages of examples/example.py:87-99.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -220,6 +221,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
 {
     ConvArgs a;
     a.ws = ws;
+    a.dbg = 0;
     a.in = L->in.ptr();
     a.out = L->out.ptr();
     a.wp = L->d_wp;
@@ -247,6 +249,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
     ConvPlan plan = choose_conv_plan(L->Mpad, P, L->ncls, L->Kpad, ws ? kSplitKWorkspaceFloats : 0);
     if (L->force_tile >= 0) plan.tile = L->force_tile;
     if (L->force_split > 0) plan.ksplit = L->force_split;
+    while (plan.ksplit > 1 && (!ws || (long)L->ncls * plan.ksplit * L->Mpad * P > kSplitKWorkspaceFloats)) --plan.ksplit;
     launch_conv_mfma(a, plan, L->ncls, s);
 }
 

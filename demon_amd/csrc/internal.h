@@ -57,6 +57,7 @@ struct ConvArgs {
     long cls_w_stride;  // Kpad*Mpad
     float *ws;          // split-K workspace [cls][slice][Mpad][P]
     int ksplit;         // number of K slices (1 = fused epilogue)
+    int dbg;            // ablation switches for tuning experiments (0 in production)
 };
 
 enum ConvTile { TILE_128x128 = 0, TILE_64x128, TILE_32x128, TILE_64x64, TILE_32x64, TILE_32x32, TILE_128x32, TILE_64x32, TILE_COUNT };
