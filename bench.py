@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
     args = ap.parse_args()
 
@@ -108,6 +109,10 @@ def main():
     # each rank owns its own shard of the global batch (rank r: pairs [r*B, (r+1)*B))
     pair, img2_2 = make_inputs(args.batch, seed=rank)
     n = ctx.upload_inputs(pair, img2_2)
+    t0 = time.perf_counter()
+    if not args.no_autotune:
+        ctx.autotune(n)   # per-layer kernel / tile / split-K selection, measured on this GPU (untimed set-up)
+    t_tune = time.perf_counter() - t0
 
     def barrier():
         if distributed:
@@ -148,7 +153,8 @@ def main():
                                    "device-resident, hipGraph on" % (args.batch, args.iterations),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "iterations": args.iterations,
                        "sharding": "independent pairs per rank, no data-path collective",
-                       "weights": "synthetic He-normal seed 1, RCCL broadcast %.1f ms (untimed)" % (1e3 * t_bcast)},
+                       "weights": "synthetic He-normal seed 1, RCCL broadcast %.1f ms (untimed)" % (1e3 * t_bcast),
+                       "autotune_s": round(t_tune, 2)},
             "pipeline_mfma_frac": value / world * GFLOP_PER_PAIR * 1e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "outputs_finite": bool(finite),
         }

@@ -41,6 +41,7 @@ SIGNATURES = {
     "demon_set_weights_blob": (_I, [_P, c_float_p, ctypes.c_int64]),
     "demon_set_weights_blob_device": (_I, [_P, _P, ctypes.c_int64]),
     "demon_set_option": (_I, [_P, ctypes.c_char_p, _I]),
+    "demon_autotune": (_I, [_P, _I]),
     "demon_bootstrap": (_I, [_P, _I, c_float_p, c_float_p, ctypes.POINTER(DemonOutputs)]),
     "demon_iterative": (_I, [_P, _I, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                              ctypes.POINTER(DemonOutputs)]),

@@ -313,6 +313,9 @@ ConvPlan choose_conv_plan(int Mpad, long pixels, int nclasses, int Kpad, long ws
     return best;
 }
 
+int conv_tile_bm(int tile) { return kTiles[tile].bm; }
+int conv_tile_bn(int tile) { return kTiles[tile].bn; }
+
 template <int BM, int BN, int WM, int WN>
 static void launch_tile(const ConvArgs &a, dim3 grid, hipStream_t stream)
 {
@@ -336,10 +339,14 @@ void launch_conv_mfma(const ConvArgs &a_in, ConvPlan plan, int nclasses, hipStre
         case TILE_64x32:   launch_tile<64, 32, 2, 1>(a, grid, stream); break;
         default:           launch_tile<32, 32, 1, 1>(a, grid, stream); break;
     }
-    if (plan.ksplit > 1) {
-        dim3 rgrid((unsigned)((P + 255) / 256), (unsigned)a.Cout, (unsigned)nclasses);
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, rgrid, dim3(256), 0, stream, a);
-    }
+    if (plan.ksplit > 1) launch_splitk_reduce(a, nclasses, stream);
+}
+
+void launch_splitk_reduce(const ConvArgs &a, int nclasses, hipStream_t stream)
+{
+    const long P = (long)a.N * a.Hp * a.Wp;
+    dim3 rgrid((unsigned)((P + 255) / 256), (unsigned)a.Cout, (unsigned)nclasses);
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, rgrid, dim3(256), 0, stream, a);
 }
 
 }  // namespace demon

@@ -1,0 +1,354 @@
+// conv_patch.hip -- patch-staged fp32-MFMA convolution for the k x 1 / 1 x k / 3 x 3 convs and the
+// 2 x 2 sub-pixel classes of the transposed convs (helpers.py:70-153, blocks_original.py:64-75, :97-110).
+//
+// Same GEMM view as conv_mfma.hip (A = weights, M = Cout; N = pixels so that NCHW stores coalesce), but the
+// B operand is not gathered element by element.  One K-step covers ALL taps of CKS input channels:
+//   * the raw input patch of the pixel tile (tile + halo, zero filled outside the image) for those CKS
+//     channels is copied to LDS once: CKS*PH*PW floats instead of NTAPS*CKS*BN im2col elements (3-9x fewer
+//     loads), with per-thread offsets / validity computed ONCE per kernel -> zero address VALU per load;
+//   * every tap reads its shifted view of the patch straight from LDS: lane j (one output pixel) reads
+//     patch[ci][y_j*sh + dy][x_j*sw + dx]; consecutive lanes are consecutive x, i.e. conflict free for
+//     stride 1 and 2-way for stride 2 (ds_read_b32 half-wave groups).
+// Reduction order per output: channel chunk major, then tap, then channel inside the chunk.
+#include <type_traits>
+
+#include "internal.h"
+
+namespace demon {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int WM, int WN, int TM, int TN, int NTAPS, int CKS, int EPT>
+__global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
+{
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BN = WN * TN * 32;
+    constexpr int KD = NTAPS * CKS;  // reduction depth of one K-step
+    constexpr int NG = KD / 2;       // MFMA groups (k pairs) per step
+    constexpr int A4 = KD * BM / 4;  // float4 chunks of the A tile
+    constexpr int APER = (A4 + NT - 1) / NT;
+    static_assert(BM == WM * TM * 32 && CKS % 2 == 0, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                           // [2][KD][BM]
+    float *Ps = smem + 2 * KD * BM;             // [2][patch_floats]
+    const int patch_floats = a.G * CKS * a.PS;
+
+    const int tid = threadIdx.x;
+    const int cls = blockIdx.z / a.ksplit;
+    const int zs = blockIdx.z - cls * a.ksplit;
+    const int m0 = blockIdx.y * BM;
+    // tile -> (image group, tile row, tile col)
+    const int tx = blockIdx.x % a.tiles_x;
+    const int tyg = blockIdx.x / a.tiles_x;
+    const int ty = tyg % a.tiles_y;
+    const int n0 = (tyg / a.tiles_y) * a.G;
+    const int y_org = ty * a.TH * a.sh + a.oy0[cls];  // input coordinates of patch element (0,0)
+    const int x_org = tx * a.TW * a.sw + a.ox0[cls];
+    const float *__restrict__ wp = a.wp + (long)cls * a.cls_w_stride;
+    const float *__restrict__ in0 = a.in + (long)n0 * a.in_n_stride;
+
+    // ---- patch loader: element e = tid + i*NT of the [G*CKS][PH*PW] patch, decoded once
+    const int plane_elems = a.PH * a.PW;
+    const int nelem = a.G * CKS * plane_elems;
+    int goff[EPT], loff[EPT];
+    unsigned okbits = 0, oklast = 0, wrbits = 0;
+    const int last_c0 = (a.nsteps_total - 1) * CKS;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = tid + i * NT;
+        goff[i] = 0;
+        loff[i] = 0;
+        if (e < nelem) {
+            const int pl = e / plane_elems, pos = e - pl * plane_elems;
+            const int g = pl / CKS, c = pl - g * CKS;
+            const int py = pos / a.PW, px = pos - py * a.PW;
+            const int gy = y_org + py, gx = x_org + px;
+            const bool ok = ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
+            if (ok) goff[i] = g * (int)a.in_n_stride + c * a.H * a.W + gy * a.W + gx;
+            loff[i] = pl * a.PS + pos;
+            wrbits |= 1u << i;
+            okbits |= (ok ? 1u : 0u) << i;
+            oklast |= ((ok && last_c0 + c < a.Cin) ? 1u : 0u) << i;
+        }
+    }
+    // ---- A loader: chunk q = tid + i*NT of the [KD][BM/4] tile; row r = tap*CKS + cl  <->  packed row tap*Cin + c0 + cl
+    int aoff[APER];
+#pragma unroll
+    for (int i = 0; i < APER; ++i) {
+        const int q = tid + i * NT;
+        const int r = q / (BM / 4), c4 = q - r * (BM / 4);
+        aoff[i] = ((r / CKS) * a.Cin + (r % CKS)) * a.Mpad + m0 + c4 * 4;
+    }
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- B fragment addressing: byte offset of this lane's pixel inside a patch buffer (+ odd-k plane)
+    const int tile_pixels = a.G * a.TH * a.TW;
+    int bbase[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int pj = (wn * TN + j) * 32 + l31;
+        if (pj >= tile_pixels) pj = 0;  // padding lanes read a valid address; masked at the store
+        const int g = pj / (a.TH * a.TW), rem = pj - g * (a.TH * a.TW);
+        const int py = rem / a.TW, px = rem - py * a.TW;
+        bbase[j] = 4 * (g * CKS * a.PS + py * a.sh * a.PW + px * a.sw + lhi * a.PS);
+    }
+    int so[NG];  // per k-pair: (even channel of the pair)*PS + tap offset, bytes (wave uniform)
+#pragma unroll
+    for (int kk = 0; kk < NG; ++kk) so[kk] = 4 * (((2 * kk) % CKS) * a.PS + a.tapoff[cls][(2 * kk) / CKS]);
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // two register sets: the global loads run TWO K-steps ahead of the MFMAs (the data of step s+1 is written
+    // to LDS at the end of step s from the set that was loaded during step s-1), so a load has a full K-step
+    // (~2300+ cycles) to return before anybody waits for it
+    float pregA[EPT], pregB[EPT];
+    floatx4 aregA[APER], aregB[APER];
+#if defined(ABL_NOLOAD) || defined(ABL_NOLOAD_P)
+    auto load_patch_one = [&](float (&preg)[EPT], int i, const float *__restrict__ base) { preg[i] = (float)i; };
+#else
+    auto load_patch_one = [&](float (&preg)[EPT], int i, const float *__restrict__ base) {
+        // only real elements: a dummy load of one shared address from every wave of every workgroup is an L2 hot spot
+        if ((wrbits >> i) & 1u) preg[i] = base[goff[i]];
+    };
+#endif
+    auto load_a_one = [&](floatx4 (&areg)[APER], int i, const float *__restrict__ base) {
+#if defined(ABL_NOLOAD) || defined(ABL_NOLOAD_A)
+        areg[i] = floatx4{1.f, 2.f, 3.f, 4.f};
+#else
+        if (A4 % NT == 0 || tid + i * NT < A4) areg[i] = *reinterpret_cast<const floatx4 *>(base + aoff[i]);
+#endif
+    };
+    auto store_tiles = [&](const float (&preg)[EPT], const floatx4 (&areg)[APER], int buf, unsigned ok) {
+#ifdef ABL_NOSTORE
+        return;
+#endif
+        float *P = Ps + buf * patch_floats;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i)
+            if ((wrbits >> i) & 1u) P[loff[i]] = ((ok >> i) & 1u) ? preg[i] : 0.0f;
+        float *A = As + buf * (KD * BM);
+#pragma unroll
+        for (int i = 0; i < APER; ++i)
+            if (A4 % NT == 0 || tid + i * NT < A4) *reinterpret_cast<floatx4 *>(A + (tid + i * NT) * 4) = areg[i];
+    };
+
+    auto kstep = [&](int buf, int next, float (&preg)[EPT], floatx4 (&areg)[APER], auto prefetch) {
+        constexpr bool PREFETCH = decltype(prefetch)::value;
+        const char *Pb = reinterpret_cast<const char *>(Ps + buf * patch_floats);
+        const float *A = As + buf * (KD * BM);
+        float av[NG][TM], bv[NG][TN];
+#pragma unroll
+        for (int kk = 0; kk < NG; ++kk) {
+            const int k = 2 * kk + lhi;
+#pragma unroll
+#ifdef ABL_NOFRAG
+            for (int i = 0; i < TM; ++i) av[kk][i] = (float)(k + i) + (float)buf;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[kk][j] = (float)(k - j) + (float)buf;
+#else
+            for (int i = 0; i < TM; ++i) av[kk][i] = A[k * BM + (wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[kk][j] = *reinterpret_cast<const float *>(Pb + bbase[j] + so[kk]);
+#endif
+        }
+        const float *__restrict__ pbase = in0 + (long)next * CKS * a.H * a.W;
+        const float *__restrict__ abase = wp + (long)next * CKS * a.Mpad;
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef USE_SETPRIO
+        __builtin_amdgcn_s_setprio(USE_SETPRIO);
+#endif
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
+            if (PREFETCH) {
+                constexpr int GH = NG / 2 > 0 ? NG / 2 : 1;  // loads behind the first half of the groups
+                if (g < GH) {
+#pragma unroll
+                    for (int i = g * EPT / GH; i < (g + 1) * EPT / GH; ++i) load_patch_one(preg, i, pbase);
+#pragma unroll
+                    for (int i = g * APER / GH; i < (g + 1) * APER / GH; ++i) load_a_one(areg, i, abase);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef USE_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+
+#ifdef START_SKEW
+    {   // phase-shift the (up to 3) workgroups that share a CU so that their load / store / barrier sections do not coincide
+        const int ph = (blockIdx.x / 256) % 3;
+        for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(START_SKEW);
+    }
+#endif
+#ifdef STATIC_PRIO
+    {   // distinct static priorities for the (up to 3) workgroups sharing a CU: the co-resident waves of a SIMD
+        // then stop marching in lock step (block b -> XCD b%8, CU (b/8)%32; b/256 separates co-residents)
+        const int pr = (blockIdx.x / STATIC_PRIO) % 3;
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    }
+#endif
+    const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
+    const int s_begin = zs * per_slice;
+    const int nsteps = min(a.nsteps_total, s_begin + per_slice) - s_begin;
+    auto okmask_of = [&](int step) { return step == a.nsteps_total - 1 ? oklast : okbits; };
+    auto clampstep = [&](int step) { return min(step, a.nsteps_total - 1); };  // run-ahead past the end re-reads the last step
+    if (nsteps > 0) {
+        // prologue: step 0 -> LDS buffer 0; step 1 -> register set B (stored at the end of step 0)
+        const float *__restrict__ pbase = in0 + (long)s_begin * CKS * a.H * a.W;
+        const float *__restrict__ abase = wp + (long)s_begin * CKS * a.Mpad;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) load_patch_one(pregA, i, pbase);
+#pragma unroll
+        for (int i = 0; i < APER; ++i) load_a_one(aregA, i, abase);
+        const int s1 = clampstep(s_begin + 1);
+        const float *__restrict__ pbase1 = in0 + (long)s1 * CKS * a.H * a.W;
+        const float *__restrict__ abase1 = wp + (long)s1 * CKS * a.Mpad;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) load_patch_one(pregB, i, pbase1);
+#pragma unroll
+        for (int i = 0; i < APER; ++i) load_a_one(aregB, i, abase1);
+        store_tiles(pregA, aregA, 0, okmask_of(s_begin));
+    }
+    __syncthreads();
+    // during step s (buffer s&1): MFMAs on step s, loads of step s+2 into the set that step s freed, then the
+    // set holding step s+1 goes to LDS buffer (s+1)&1.  Pairs of steps keep the set indices static.
+    int s = 0;
+    for (; s + 2 < nsteps; s += 2) {
+        kstep(0, clampstep(s_begin + s + 2), pregA, aregA, std::true_type{});
+        store_tiles(pregB, aregB, 1, okmask_of(s_begin + s + 1));
+        __syncthreads();
+        kstep(1, clampstep(s_begin + s + 3), pregB, aregB, std::true_type{});
+        store_tiles(pregA, aregA, 0, okmask_of(s_begin + s + 2));
+        __syncthreads();
+    }
+    if (s + 1 < nsteps) {
+        kstep(0, 0, pregA, aregA, std::false_type{});
+        store_tiles(pregB, aregB, 1, okmask_of(s_begin + s + 1));
+        __syncthreads();
+        ++s;
+    }
+    if (nsteps > 0) kstep(s & 1, 0, pregA, aregA, std::false_type{});
+
+    // ---- epilogue
+    const int opy = cls >> 1, opx = cls & 1;
+    const long plane = (long)a.Ho * a.Wo;
+    const long Ptot = (long)a.N * a.Hp * a.Wp;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int pj = (wn * TN + j) * 32 + l31;
+        if (pj >= tile_pixels) continue;
+        const int g = pj / (a.TH * a.TW), rem = pj - g * (a.TH * a.TW);
+        const int py = rem / a.TW, px = rem - py * a.TW;
+        const int y = ty * a.TH + py, x = tx * a.TW + px, n = n0 + g;
+        if (y >= a.Hp || x >= a.Wp || n >= a.N) continue;
+        if (a.ksplit > 1) {
+            const long p = ((long)n * a.Hp + y) * a.Wp + x;
+            float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * Ptot + p;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    ws[(long)co * Ptot] = acc[i][j][r];
+                }
+        } else {
+            float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)(y * a.osy + opy) * a.Wo + (x * a.osx + opx);
+            const float sc = a.scale ? a.scale[n] : 1.0f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (co < a.Cout) {
+                        float v = acc[i][j][r] + a.bias[co];
+                        if (a.act) v = v >= 0.0f ? v : 0.1f * v;
+                        if (co == 0) v *= sc;
+                        ob[(long)co * plane] = v;
+                    }
+                }
+        }
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------------
+struct PatchTile { int bm, bn, threads; };
+static const PatchTile kPatchTiles[PTILE_COUNT] = {{128, 128, 256}, {64, 128, 256}, {32, 128, 256}, {64, 64, 256}};
+
+int patch_cks(int ntaps)
+{
+    switch (ntaps) {
+        case 3: return 8;
+        case 4: return 4;
+        case 5: return 4;
+        case 7: return 2;
+        case 9: return 2;
+        default: return 0;
+    }
+}
+
+int patch_tile_bm(int tile) { return kPatchTiles[tile].bm; }
+int patch_tile_bn(int tile) { return kPatchTiles[tile].bn; }
+
+size_t patch_lds_bytes(int tile, int ntaps, int G, int PS)
+{
+    const int cks = patch_cks(ntaps);
+    return sizeof(float) * (2ul * ntaps * cks * kPatchTiles[tile].bm + 2ul * G * cks * PS);
+}
+
+template <int BM, int WM, int WN, int TM, int TN, int EPT>
+static void launch_patch_taps(const PatchArgs &a, int ntaps, dim3 grid, size_t lds, hipStream_t s)
+{
+    constexpr int NT = 64 * WM * WN;
+    switch (ntaps) {
+        case 3: hipLaunchKernelGGL((conv_patch_kernel<BM, WM, WN, TM, TN, 3, 8, EPT>), grid, dim3(NT), lds, s, a); break;
+        case 4: hipLaunchKernelGGL((conv_patch_kernel<BM, WM, WN, TM, TN, 4, 4, EPT>), grid, dim3(NT), lds, s, a); break;
+        case 5: hipLaunchKernelGGL((conv_patch_kernel<BM, WM, WN, TM, TN, 5, 4, EPT>), grid, dim3(NT), lds, s, a); break;
+        case 7: hipLaunchKernelGGL((conv_patch_kernel<BM, WM, WN, TM, TN, 7, 2, EPT>), grid, dim3(NT), lds, s, a); break;
+        case 9: hipLaunchKernelGGL((conv_patch_kernel<BM, WM, WN, TM, TN, 9, 2, EPT>), grid, dim3(NT), lds, s, a); break;
+        default: break;
+    }
+}
+
+template <int BM, int WM, int WN, int TM, int TN>
+static void launch_patch_ept(const PatchArgs &a, int ntaps, dim3 grid, size_t lds, hipStream_t s)
+{
+    const long elems = (long)a.G * patch_cks(ntaps) * a.PH * a.PW;
+    const int per_thread = (int)((elems + 64 * WM * WN - 1) / (64 * WM * WN));
+    if (per_thread <= 2) launch_patch_taps<BM, WM, WN, TM, TN, 2>(a, ntaps, grid, lds, s);
+    else if (per_thread <= 4) launch_patch_taps<BM, WM, WN, TM, TN, 4>(a, ntaps, grid, lds, s);
+    else launch_patch_taps<BM, WM, WN, TM, TN, PATCH_EPT>(a, ntaps, grid, lds, s);
+}
+
+void launch_conv_patch(const PatchArgs &a, int tile, int ntaps, int nclasses, hipStream_t stream)
+{
+    const PatchTile ti = kPatchTiles[tile];
+    const int groups = (a.N + a.G - 1) / a.G;
+    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / ti.bm), (unsigned)(nclasses * a.ksplit));
+    const size_t lds = patch_lds_bytes(tile, ntaps, a.G, a.PS);
+    switch (tile) {
+        case PTILE_128x128: launch_patch_ept<128, 2, 2, 2, 2>(a, ntaps, grid, lds, stream); break;
+        case PTILE_64x128:  launch_patch_ept<64, 2, 2, 1, 2>(a, ntaps, grid, lds, stream); break;
+        case PTILE_32x128:  launch_patch_ept<32, 1, 4, 1, 1>(a, ntaps, grid, lds, stream); break;
+        default:            launch_patch_ept<64, 2, 2, 1, 1>(a, ntaps, grid, lds, stream); break;
+    }
+}
+
+}  // namespace demon

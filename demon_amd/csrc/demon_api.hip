@@ -31,12 +31,15 @@ struct Layer {
     int Cin = 0, Cout = 0, kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0, act = 0;
     View in, out;
     const float *scale = nullptr;
-    int K = 0, Kpad = 0, Mpad = 0, ncls = 1;
+    int K = 0, Kpad = 0, Krows = 0, Mpad = 0, ncls = 1;
     float *d_wp = nullptr, *d_bias = nullptr;
     KEntry *d_ktab = nullptr;
     bool have_kernel = false, have_bias = false;
     std::vector<int64_t> kernel_dims;  // TF layout
     int force_tile = -1, force_split = 0;  // tuning override (demon_bench_layer)
+    // autotuned choice per batch size: kind 0 = im2col kernel (tile, ksplit), 1 = patch kernel (patch tile)
+    struct Tuned { int kind, tile, ksplit; };
+    std::map<int, Tuned> tuned;
 };
 
 struct Step {
@@ -108,7 +111,9 @@ View buffer(demon_ctx *c, const std::string &key, int C, int H, int W)
     auto it = c->buffers.find(key);
     if (it != c->buffers.end()) return it->second;
     View v;
-    v.base = dev_alloc(c, sizeof(float) * (size_t)c->max_batch * C * H * W);
+    // + 8 planes of slack: the patch kernel's last channel chunk may read (and discard) up to CKS-1 planes
+    // past the last channel of the last sample
+    v.base = dev_alloc(c, sizeof(float) * ((size_t)c->max_batch * C * H * W + 8ul * H * W));
     v.Ctot = C; v.c0 = 0; v.C = C; v.H = H; v.W = W;
     c->buffers[key] = v;
     return v;
@@ -179,11 +184,12 @@ bool plan_layer(demon_ctx *c, Layer *L)
         for (int k = 0; k < L->K; ++k) tab[k] = KEntry{k, pack(0, 0)};
     }
     L->d_ktab = (KEntry *)dev_alloc(c, tab.size() * sizeof(KEntry));
-    L->d_wp = dev_alloc(c, sizeof(float) * (size_t)L->ncls * L->Kpad * L->Mpad);
+    L->Krows = L->Kpad + 16;  // 16 zero rows of slack: the patch kernel's last channel chunk may read past K
+    L->d_wp = dev_alloc(c, sizeof(float) * (size_t)L->ncls * L->Krows * L->Mpad);
     L->d_bias = dev_alloc(c, sizeof(float) * L->Mpad);
     if (!L->d_ktab || !L->d_wp || !L->d_bias) return false;
     if (hipMemcpy(L->d_ktab, tab.data(), tab.size() * sizeof(KEntry), hipMemcpyHostToDevice) != hipSuccess) return false;
-    if (hipMemset(L->d_wp, 0, sizeof(float) * (size_t)L->ncls * L->Kpad * L->Mpad) != hipSuccess) return false;
+    if (hipMemset(L->d_wp, 0, sizeof(float) * (size_t)L->ncls * L->Krows * L->Mpad) != hipSuccess) return false;
     if (hipMemset(L->d_bias, 0, sizeof(float) * L->Mpad) != hipSuccess) return false;
     return true;
 }
@@ -191,7 +197,7 @@ bool plan_layer(demon_ctx *c, Layer *L)
 // TF layout -> packed [cls][Kpad][Mpad] (host side, then one upload)
 int upload_kernel(demon_ctx *c, Layer *L, const float *w)
 {
-    std::vector<float> wp((size_t)L->ncls * L->Kpad * L->Mpad, 0.0f);
+    std::vector<float> wp((size_t)L->ncls * L->Krows * L->Mpad, 0.0f);
     if (L->kind == Layer::CONV || L->kind == Layer::DENSE) {
         // HWIO [kh][kw][Cin][Cout] (dense: [in][out]) is already [k][co] with k = (a*kw+b)*Cin+ci
         for (int k = 0; k < L->K; ++k) memcpy(&wp[(size_t)k * L->Mpad], w + (size_t)k * L->Cout, sizeof(float) * L->Cout);
@@ -204,7 +210,7 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
                     const int a = tap_a[py][ty], b = tap_a[px][tx];
                     for (int ci = 0; ci < L->Cin; ++ci) {
                         const int k = (ty * 2 + tx) * L->Cin + ci;
-                        float *dst = &wp[((size_t)cls * L->Kpad + k) * L->Mpad];
+                        float *dst = &wp[((size_t)cls * L->Krows + k) * L->Mpad];
                         for (int co = 0; co < L->Cout; ++co) dst[co] = w[(((size_t)a * 4 + b) * L->Cout + co) * L->Cin + ci];
                     }
                 }
@@ -217,9 +223,8 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
 
 constexpr long kSplitKWorkspaceFloats = 16l << 20;  // 64 MiB
 
-void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
+void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
 {
-    ConvArgs a;
     a.ws = ws;
     a.dbg = 0;
     a.in = L->in.ptr();
@@ -239,18 +244,219 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
     a.Wo = L->out.W;
     a.out_n_stride = L->out.n_stride();
     a.act = L->act;
-    a.cls_w_stride = (long)L->Kpad * L->Mpad;
+    a.cls_w_stride = (long)L->Krows * L->Mpad;
+    a.ksplit = 1;
     if (L->kind == Layer::DECONV) {
         a.Hp = L->in.H; a.Wp = L->in.W; a.sy = 1; a.sx = 1; a.osy = 2; a.osx = 2;
     } else {
         a.Hp = L->out.H; a.Wp = L->out.W; a.sy = L->sh; a.sx = L->sw; a.osy = 1; a.osx = 1;
     }
+}
+
+// Geometry of the patch-staged kernel for one layer and batch size: picks the Cout x pixel tile, the pixel
+// tile shape (G images x TH rows x TW cols) with the least staged input per output pixel, and split-K.
+struct PatchPlan { bool ok = false; int tile = 0, ntaps = 0; PatchArgs a; };
+
+bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile = -1)
+{
+    static const int enabled = getenv("DEMON_CONV_PATCH") ? atoi(getenv("DEMON_CONV_PATCH")) : 1;
+    pp.ok = false;
+    if (!enabled || L->kind == Layer::DENSE) return false;
+    const int ntaps = L->kind == Layer::DECONV ? 4 : L->kh * L->kw;
+    const int cks = patch_cks(ntaps);
+    if (!cks) return false;
+    if (L->kind == Layer::CONV && L->kh > 1 && L->kw > 1 && !(L->kh == 3 && L->kw == 3)) return false;
+    const int chunks = (L->Cin + cks - 1) / cks;
+    if ((float)L->Cin / (chunks * cks) < 0.7f) return false;  // too much zero padding in K: the im2col kernel is better
+    ConvArgs ca;
+    fill_conv_args(L, n, ws, ca);
+    const int Hp = ca.Hp, Wp = ca.Wp, sh = ca.sy, sw = ca.sx;
+    int ext_y, ext_x;  // tap extent
+    if (L->kind == Layer::DECONV) { ext_y = 2; ext_x = 2; } else { ext_y = L->kh; ext_x = L->kw; }
+    float best_cost = 1e30f;
+    for (int tile = 0; tile < PTILE_COUNT; ++tile) {
+        if (only_tile >= 0 && tile != only_tile) continue;
+        const int bm = patch_tile_bm(tile), bn = patch_tile_bn(tile), nt = 256;
+        if (L->Mpad % bm) continue;
+        for (int tw_sel = 0; tw_sel < 4; ++tw_sel) {
+            int TW = tw_sel == 0 ? (Wp < bn ? Wp : bn) : (bn >> tw_sel);  // Wp/bn, bn/2, bn/4, bn/8
+            if (TW < 8 || TW > Wp || TW > bn) continue;
+            int TH = bn / TW;
+            if (TH > Hp) TH = Hp;
+            int G = 1;
+            if (TH == Hp && TW == Wp) { G = bn / (TH * TW); if (G < 1) G = 1; if (G > n) G = n; }
+            const int PH = (TH - 1) * sh + ext_y, PW = (TW - 1) * sw + ext_x, PS = PH * PW;
+            const long elems = (long)G * cks * PS;
+            if ((elems + nt - 1) / nt > PATCH_EPT) continue;
+            if (patch_lds_bytes(tile, ntaps, G, PS) > 64 * 1024) continue;
+            const int tiles_y = (Hp + TH - 1) / TH, tiles_x = (Wp + TW - 1) / TW, groups = (n + G - 1) / G;
+            const double useful = (double)n * Hp * Wp;
+            const double tiles = (double)groups * tiles_y * tiles_x;
+            const double mfma_waste = tiles * bn / useful;          // >= 1: padded MFMA columns
+            const double staged = tiles * elems / useful / cks;     // staged input floats per output pixel per channel
+            // cost model: MFMA time dominates; staging adds ~ (staged / ntaps) relative to one MFMA column, and small Cout
+            // tiles pay more for it; calibrated loosely on layer sweeps
+            const float cost = (float)(mfma_waste * (1.0 + 0.35 * staged / ntaps * (128.0 / bm)) * (bm == 128 ? 1.0 : (bm == 64 ? 1.04 : 1.10)));
+            if (cost < best_cost) {
+                best_cost = cost;
+                pp.tile = tile;
+                PatchArgs &a = pp.a;
+                a.G = G; a.TH = TH; a.TW = TW; a.tiles_y = tiles_y; a.tiles_x = tiles_x; a.PH = PH; a.PW = PW; a.PS = PS;
+                pp.ok = true;
+            }
+        }
+    }
+    if (!pp.ok) return false;
+    pp.ntaps = ntaps;
+    PatchArgs &a = pp.a;
+    a.in = ca.in; a.out = ca.out; a.wp = ca.wp; a.bias = ca.bias; a.scale = ca.scale; a.ws = ws;
+    a.N = n; a.Cin = L->Cin; a.H = ca.H; a.W = ca.W; a.in_n_stride = ca.in_n_stride;
+    a.Hp = Hp; a.Wp = Wp; a.sh = sh; a.sw = sw;
+    a.Cout = L->Cout; a.Mpad = L->Mpad; a.cls_w_stride = ca.cls_w_stride;
+    a.Ho = ca.Ho; a.Wo = ca.Wo; a.out_n_stride = ca.out_n_stride; a.osy = ca.osy; a.osx = ca.osx;
+    a.act = L->act; a.nsteps_total = chunks;
+    for (int cls = 0; cls < 4; ++cls) {
+        if (L->kind == Layer::DECONV) {
+            static const int tap_d[2][2] = {{0, -1}, {1, 0}};
+            const int py = cls >> 1, px = cls & 1;
+            a.oy0[cls] = py ? 0 : -1;
+            a.ox0[cls] = px ? 0 : -1;
+            for (int ty = 0; ty < 2; ++ty)
+                for (int tx = 0; tx < 2; ++tx)
+                    a.tapoff[cls][ty * 2 + tx] = (tap_d[py][ty] - a.oy0[cls]) * a.PW + (tap_d[px][tx] - a.ox0[cls]);
+        } else {
+            a.oy0[cls] = -L->ph;
+            a.ox0[cls] = -L->pw;
+            for (int ta = 0; ta < L->kh; ++ta)
+                for (int tb = 0; tb < L->kw; ++tb) a.tapoff[cls][ta * L->kw + tb] = ta * a.PW + tb;
+        }
+    }
+    // split-K over channel chunks when the grid is too small to fill the chip
+    const long groups = (n + a.G - 1) / a.G;
+    const long wgs = groups * a.tiles_y * a.tiles_x * (L->Mpad / patch_tile_bm(pp.tile)) * L->ncls;
+    int split = 1;
+    if (wgs < 384) {
+        split = (int)((512 + wgs - 1) / wgs);
+        const int smax = chunks / 4 > 1 ? chunks / 4 : 1;
+        if (split > smax) split = smax;
+        const long P = (long)n * Hp * Wp;
+        while (split > 1 && (!ws || (long)L->ncls * split * L->Mpad * P > kSplitKWorkspaceFloats)) --split;
+    }
+    a.ksplit = split;
+    return true;
+}
+
+void launch_patch_plan(const Layer *L, PatchPlan &pp, ConvArgs &a, long P, float *ws, hipStream_t s)
+{
+    while (pp.a.ksplit > 1 && (!ws || (long)L->ncls * pp.a.ksplit * L->Mpad * P > kSplitKWorkspaceFloats)) --pp.a.ksplit;
+    launch_conv_patch(pp.a, pp.tile, pp.ntaps, L->ncls, s);
+    if (pp.a.ksplit > 1) {
+        a.ksplit = pp.a.ksplit;
+        launch_splitk_reduce(a, L->ncls, s);
+    }
+}
+
+void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
+{
+    ConvArgs a;
+    fill_conv_args(L, n, ws, a);
     const long P = (long)n * a.Hp * a.Wp;
+    auto clamp_split = [&](int k) {
+        while (k > 1 && (!ws || (long)L->ncls * k * L->Mpad * P > kSplitKWorkspaceFloats)) --k;
+        return k;
+    };
+    // test hook: DEMON_FORCE_PLAN="kind,tile,ksplit" forces one kernel variant for every layer it applies to
+    if (const char *fp = getenv("DEMON_FORCE_PLAN")) {
+        int kind = 0, tile = 0, ks = 1;
+        if (sscanf(fp, "%d,%d,%d", &kind, &tile, &ks) == 3) {
+            if (kind == 1) {
+                PatchPlan pp;
+                if (tile >= 0 && tile < PTILE_COUNT && plan_patch(L, n, ws, pp, tile)) {
+                    if (ks > 0) pp.a.ksplit = ks < pp.a.nsteps_total ? ks : pp.a.nsteps_total;
+                    launch_patch_plan(L, pp, a, P, ws, s);
+                    return;
+                }
+            } else if (tile >= 0 && tile < TILE_COUNT && L->Mpad % conv_tile_bm(tile) == 0) {
+                launch_conv_mfma(a, ConvPlan{tile, clamp_split(ks < 1 ? 1 : (ks > L->Kpad / 16 ? L->Kpad / 16 : ks))}, L->ncls, s);
+                return;
+            }
+        }
+    }
+    if (L->force_tile < 0) {
+        auto it = L->tuned.find(n);
+        if (it != L->tuned.end()) {  // measured choice (demon_autotune)
+            const Layer::Tuned &t = it->second;
+            if (t.kind == 1) {
+                PatchPlan pp;
+                if (plan_patch(L, n, ws, pp, t.tile)) { launch_patch_plan(L, pp, a, P, ws, s); return; }
+            } else {
+                launch_conv_mfma(a, ConvPlan{t.tile, clamp_split(t.ksplit)}, L->ncls, s);
+                return;
+            }
+        }
+    }
+    if (L->force_tile < 0 || L->force_tile >= 100) {
+        PatchPlan pp;
+        if (plan_patch(L, n, ws, pp, L->force_tile >= 100 ? L->force_tile - 100 : -1)) {
+            if (L->force_split > 0) pp.a.ksplit = L->force_split;
+            launch_patch_plan(L, pp, a, P, ws, s);
+            return;
+        }
+    }
     ConvPlan plan = choose_conv_plan(L->Mpad, P, L->ncls, L->Kpad, ws ? kSplitKWorkspaceFloats : 0);
-    if (L->force_tile >= 0) plan.tile = L->force_tile;
+    if (L->force_tile >= 0 && L->force_tile < TILE_COUNT) plan.tile = L->force_tile;
     if (L->force_split > 0) plan.ksplit = L->force_split;
-    while (plan.ksplit > 1 && (!ws || (long)L->ncls * plan.ksplit * L->Mpad * P > kSplitKWorkspaceFloats)) --plan.ksplit;
+    plan.ksplit = clamp_split(plan.ksplit);
     launch_conv_mfma(a, plan, L->ncls, s);
+}
+
+// Measures every applicable (kernel, tile, split-K) variant of one layer at batch n and remembers the fastest.
+int autotune_layer(demon_ctx *c, Layer *L, int n)
+{
+    struct Cand { int kind, tile, ksplit; };
+    std::vector<Cand> cands;
+    ConvArgs a;
+    fill_conv_args(L, n, c->d_ws, a);
+    const long P = (long)n * a.Hp * a.Wp;
+    const ConvPlan heur = choose_conv_plan(L->Mpad, P, L->ncls, L->Kpad, kSplitKWorkspaceFloats);
+    for (int t = 0; t < TILE_COUNT; ++t) {
+        if (L->Mpad % conv_tile_bm(t)) continue;
+        if (conv_tile_bn(t) > 32 && P * 2 <= conv_tile_bn(t)) continue;
+        const long wgs = (long)(L->Mpad / conv_tile_bm(t)) * ((P + conv_tile_bn(t) - 1) / conv_tile_bn(t)) * L->ncls;
+        const int nsteps = L->Kpad / 16;
+        for (int ks : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) {
+            if (ks > 1 && (ks > nsteps / 4 || wgs * ks > 2048 || (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
+            if (wgs * ks < 96 && !(t == heur.tile && ks == heur.ksplit)) continue;  // hopeless: less than 3/8 of the CUs busy
+            cands.push_back({0, t, ks});
+        }
+    }
+    for (int t = 0; t < PTILE_COUNT; ++t) {
+        PatchPlan pp;
+        if (plan_patch(L, n, c->d_ws, pp, t)) cands.push_back({1, t, 0});
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;
+    float best = 1e30f;
+    Layer::Tuned best_t{0, heur.tile, heur.ksplit};
+    for (const Cand &cd : cands) {
+        L->tuned[n] = Layer::Tuned{cd.kind, cd.tile, cd.ksplit};
+        run_layer(L, n, c->stream, c->d_ws);  // warm-up
+        hipEventRecord(e0, c->stream);
+        for (int i = 0; i < 3; ++i) run_layer(L, n, c->stream, c->d_ws);
+        hipEventRecord(e1, c->stream);
+        if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return DEMON_ERR_HIP; }
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) { best = ms; best_t = Layer::Tuned{cd.kind, cd.tile, cd.ksplit}; }
+    }
+    if (const char *pk = getenv("DEMON_TUNE_PICK")) {  // test hook: deterministic choice = candidate index
+        const Cand &cd = cands[(size_t)atoi(pk) % cands.size()];
+        best_t = Layer::Tuned{cd.kind, cd.tile, cd.ksplit};
+    }
+    L->tuned[n] = best_t;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return DEMON_OK;
 }
 
 // ---- topology builder ---------------------------------------------------------------------------------
@@ -743,6 +949,19 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }
 
+int demon_autotune(demon_ctx *c, int n)
+{
+    if (!c || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "batch size out of range [1, max_batch]");
+    hipSetDevice(c->device);
+    for (auto &g : c->graphs) hipGraphExecDestroy(g.second);  // captured launches embed the old choices
+    c->graphs.clear();
+    for (auto &L : c->layers) {
+        int r = autotune_layer(c, L.get(), n);
+        if (r) return fail(c, r, "autotune failed at layer " + L->name);
+    }
+    return DEMON_OK;
+}
+
 int demon_upload_inputs(demon_ctx *c, int n, const float *image_pair, const float *image2_2)
 {
     int r = check_batch(c, n);
@@ -1035,7 +1254,7 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
 int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw,
                       int tile, int ksplit, int iters, float *avg_ms, double *flops)
 {
-    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || tile >= TILE_COUNT) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || tile >= 100 + PTILE_COUNT) return fail(c, DEMON_ERR_INVALID, "bad argument");
     hipSetDevice(c->device);
     demon_ctx scratch;
     scratch.device = c->device;
@@ -1055,7 +1274,7 @@ int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int
     if (!L.in.base || !L.out.base || !plan_layer(&scratch, &L)) rc = fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
     if (!rc) {
         // deterministic pseudo-random fill (full-range values: zero-filled operands would clock higher)
-        const size_t nin = (size_t)n * cin * h * wd, nw = (size_t)L.ncls * L.Kpad * L.Mpad;
+        const size_t nin = (size_t)n * cin * h * wd, nw = (size_t)L.ncls * L.Krows * L.Mpad;
         std::vector<float> hin(nin), hw(nw);
         unsigned st = 12345u;
         auto rnd = [&st]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };

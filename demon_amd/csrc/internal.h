@@ -65,6 +65,41 @@ struct ConvPlan { int tile; int ksplit; };
 
 void launch_conv_mfma(const ConvArgs &a, ConvPlan plan, int nclasses, hipStream_t stream);
 ConvPlan choose_conv_plan(int Mpad, long pixels, int nclasses, int Kpad, long ws_floats);
+int conv_tile_bm(int tile);
+int conv_tile_bn(int tile);
+
+void launch_splitk_reduce(const ConvArgs &a, int nclasses, hipStream_t stream);
+
+// ---- patch-staged convolution (conv_patch.hip) ---------------------------------------------------------
+constexpr int PATCH_EPT = 8;  // patch elements a thread stages per K-step
+struct PatchArgs {
+    const float *in;
+    float *out;
+    const float *wp;     // packed weights [cls][rows][Mpad], row = tap*Cin + ci (same packing as conv_mfma)
+    const float *bias;
+    const float *scale;
+    float *ws;
+    int N, Cin, H, W;
+    long in_n_stride;
+    int Hp, Wp;          // pixel grid per image
+    int G, TH, TW, tiles_y, tiles_x;  // pixel tile = G images x TH rows x TW cols
+    int sh, sw;
+    int oy0[4], ox0[4];  // per class: input coordinates of patch element (0,0) relative to the tile anchor
+    int PH, PW, PS;      // patch rows / cols / plane stride (floats)
+    int tapoff[4][9];    // per class, per tap: float offset inside a plane
+    int Cout, Mpad;
+    long cls_w_stride;
+    int Ho, Wo;
+    long out_n_stride;
+    int osy, osx;
+    int act, ksplit, nsteps_total;
+};
+enum PatchTileId { PTILE_128x128 = 0, PTILE_64x128, PTILE_32x128, PTILE_64x64, PTILE_COUNT };
+int patch_cks(int ntaps);
+int patch_tile_bm(int tile);
+int patch_tile_bn(int tile);
+size_t patch_lds_bytes(int tile, int ntaps, int G, int PS);
+void launch_conv_patch(const PatchArgs &a, int tile, int ntaps, int nclasses, hipStream_t stream);
 
 // ---- op launchers (ops.hip) --------------------------------------------------------------------
 void launch_depth_to_flow(float *out, const float *depth, long depth_n_stride, const float *intrinsics,

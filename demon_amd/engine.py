@@ -64,10 +64,13 @@ class DemonContext:
 
     def set_weights(self, weights):
         """weights: dict tf_name -> array in TF layout; every variable must be present."""
-        for name, shape in self.variables():
+        variables = self.variables()
+        checked = []
+        for name, shape in variables:   # validate everything first: a failed call must not leave a half-loaded model
             if name not in weights:
                 raise DemonError("missing variable %s" % name)
-            w = _f32(weights[name], shape, name)
+            checked.append((name, shape, _f32(weights[name], shape, name)))
+        for name, shape, w in checked:
             dims = (ctypes.c_int64 * len(shape))(*shape)
             self._check(self.lib.demon_set_weight(self.h, name.encode(), _fp(w), dims, len(shape)))
 
@@ -80,6 +83,10 @@ class DemonContext:
 
     def set_weights_blob_device(self, device_ptr, nfloats):
         self._check(self.lib.demon_set_weights_blob_device(self.h, ctypes.c_void_p(device_ptr), nfloats))
+
+    def autotune(self, n):
+        """measure every kernel variant per layer at batch n and keep the fastest (launch plans only)"""
+        self._check(self.lib.demon_autotune(self.h, int(n)))
 
     def set_option(self, key, value):
         self._check(self.lib.demon_set_option(self.h, key.encode(), int(value)))

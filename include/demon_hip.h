@@ -74,6 +74,9 @@ int demon_set_weights_blob_device(demon_ctx *ctx, const void *device_blob, int64
 /* ---- options ---------------------------------------------------------------------------------
  * "hipgraph" 0/1 (default 1), "flow_to_depth_method" 0 = DLT/SVD, 1 = closed form (default 0)    */
 int demon_set_option(demon_ctx *ctx, const char *key, int value);
+/* Times every applicable kernel variant (im2col / patch-staged, tile shape, split-K) of every layer at batch n on
+ * this GPU and keeps the fastest per layer (~1 s; results do not change, only launch plans). */
+int demon_autotune(demon_ctx *ctx, int n);
 
 /* ---- networks, host buffers in / host buffers out ------------------------------------------------
  * demon_bootstrap  replaces BootstrapNet.eval   (networks_original.py:60-88)

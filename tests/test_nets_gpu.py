@@ -166,3 +166,15 @@ def test_error_reporting(gpu_ctx):
         gpu_ctx.set_option("no_such_option", 1)
     with pytest.raises(DemonError):
         gpu_ctx.set_weights({"netFlow1/conv1y/kernel": np.zeros((9, 1, 6, 32), np.float32)})  # incomplete
+
+
+def test_autotune_keeps_results(gpu_ctx, ref):
+    """demon_autotune only changes launch plans (kernel family / tile / split-K): outputs stay within tolerance"""
+    pair, img2_2 = make_inputs(2, seed=13)
+    before = gpu_ctx.full(pair, img2_2, iterations=2)
+    gpu_ctx.autotune(2)
+    after = gpu_ctx.full(pair, img2_2, iterations=2)
+    want = ref.full(pair, img2_2, iterations=2)
+    _cmp(after, want, KEYS + ("predict_depth0",))
+    for k in KEYS + ("predict_depth0",):
+        assert rel_l1(after[k], before[k]) < 1e-4, k

@@ -1,0 +1,55 @@
+"""Every kernel variant the autotuner may pick (im2col / patch-staged, each tile shape, several split-K factors)
+must give the same layer result.  DEMON_FORCE_PLAN is a test hook read by the library at launch time."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_l1
+
+pytestmark = pytest.mark.gpu
+
+# (kind, cin, cout, kh, kw, sh, sw, H, W)
+LAYERS = [
+    ("conv", 32, 32, 1, 9, 1, 2, 12, 64), ("conv", 64, 64, 3, 1, 1, 1, 48, 64), ("conv", 64, 128, 5, 1, 2, 1, 48, 64),
+    ("conv", 128, 128, 1, 5, 1, 2, 24, 64), ("conv", 256, 256, 3, 1, 1, 1, 12, 16), ("conv", 512, 512, 1, 3, 1, 1, 6, 8),
+    ("conv", 256, 512, 5, 1, 2, 1, 12, 16), ("conv", 32, 64, 7, 1, 2, 1, 24, 32), ("conv", 128, 24, 3, 3, 1, 1, 48, 64),
+    ("conv", 64, 64, 3, 3, 1, 1, 24, 32), ("conv", 32, 64, 3, 3, 2, 2, 24, 32), ("conv", 512, 24, 3, 3, 1, 1, 6, 8),
+    ("conv", 6, 32, 9, 1, 2, 1, 48, 64), ("conv", 24, 4, 3, 3, 1, 1, 6, 8),
+    ("deconv", 512, 256, 0, 0, 0, 0, 6, 8), ("deconv", 514, 128, 0, 0, 0, 0, 12, 16), ("deconv", 128, 32, 0, 0, 0, 0, 24, 32),
+]
+
+
+def _ref(kind, x, w, b, stride):
+    import torch
+    import torch.nn.functional as F
+    if kind == "deconv":
+        y = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(np.ascontiguousarray(w.transpose(3, 2, 0, 1))), torch.from_numpy(b), stride=2, padding=1)
+    else:
+        kh, kw = w.shape[0], w.shape[1]
+        xt = F.pad(torch.from_numpy(x), (kw // 2, kw // 2, kh // 2, kh // 2))
+        y = F.conv2d(xt, torch.from_numpy(np.ascontiguousarray(w.transpose(3, 2, 0, 1))), torch.from_numpy(b), stride=stride)
+    return torch.where(y >= 0, y, 0.1 * y).numpy()
+
+
+@pytest.mark.parametrize("layer", LAYERS)
+def test_all_variants_agree(gpu_ctx, layer):
+    kind, cin, cout, kh, kw, sh, sw, H, W = layer
+    rng = np.random.default_rng(30)
+    n = 3
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    if kind == "deconv":
+        w = (rng.standard_normal((4, 4, cout, cin)) / np.sqrt(4 * cin)).astype(np.float32)
+    else:
+        w = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref(kind, x, w, b, (sh, sw))
+    plans = [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(4) for ks in (0, 2, 3, 5)]
+    try:
+        for plan in plans:
+            os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
+            got = gpu_ctx.deconv4x4s2(x, w, b, lrelu=True) if kind == "deconv" else gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
+            err = rel_l1(got, want)
+            assert err < 1e-5, "plan %s: rel L1 %.3e" % (plan, err)
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
