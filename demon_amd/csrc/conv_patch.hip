@@ -209,44 +209,78 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     const int s_begin = zs * per_slice;
     const int nsteps = min(a.nsteps_total, s_begin + per_slice) - s_begin;
     auto okmask_of = [&](int step) { return step == a.nsteps_total - 1 ? oklast : okbits; };
-    auto clampstep = [&](int step) { return min(step, a.nsteps_total - 1); };  // run-ahead past the end re-reads the last step
+    // optional K rotation (-DK_ROTATE): workgroup b starts at channel chunk (b mod nsteps) so that the workgroups of one
+    // Cout tile do not all read the same weight rows at the same time.  Measured: no gain on MI355X, off by default.
+#ifndef K_ROTATE
+    const int rot = 0;
+#else
+    const int rot = nsteps > 0 ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nsteps) : 0;
+#endif
+    auto phys = [&](int x) {  // logical step of this slice -> chunk index; run-ahead past the end re-reads the last one
+        x = min(x, nsteps - 1);
+        int r = x + rot;
+        if (r >= nsteps) r -= nsteps;
+        return s_begin + r;
+    };
+#ifdef PREFETCH_DIST1
     if (nsteps > 0) {
-        // prologue: step 0 -> LDS buffer 0; step 1 -> register set B (stored at the end of step 0)
-        const float *__restrict__ pbase = in0 + (long)s_begin * CKS * a.H * a.W;
-        const float *__restrict__ abase = wp + (long)s_begin * CKS * a.Mpad;
+        const int p0s = phys(0);
+        const float *__restrict__ pbase = in0 + (long)p0s * CKS * a.H * a.W;
+        const float *__restrict__ abase = wp + (long)p0s * CKS * a.Mpad;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) load_patch_one(pregA, i, pbase);
 #pragma unroll
         for (int i = 0; i < APER; ++i) load_a_one(aregA, i, abase);
-        const int s1 = clampstep(s_begin + 1);
+        store_tiles(pregA, aregA, 0, okmask_of(p0s));
+    }
+    __syncthreads();
+    for (int s = 0; s + 1 < nsteps; ++s) {
+        kstep(s & 1, phys(s + 1), pregA, aregA, std::true_type{});
+        store_tiles(pregA, aregA, (s & 1) ^ 1, okmask_of(phys(s + 1)));
+        __syncthreads();
+    }
+    if (nsteps > 0) kstep((nsteps - 1) & 1, 0, pregA, aregA, std::false_type{});
+    (void)pregB; (void)aregB;
+#else
+    if (nsteps > 0) {
+        // prologue: step 0 -> LDS buffer 0; step 1 -> register set B (stored at the end of step 0)
+        const int p0s = phys(0);
+        const float *__restrict__ pbase = in0 + (long)p0s * CKS * a.H * a.W;
+        const float *__restrict__ abase = wp + (long)p0s * CKS * a.Mpad;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) load_patch_one(pregA, i, pbase);
+#pragma unroll
+        for (int i = 0; i < APER; ++i) load_a_one(aregA, i, abase);
+        const int s1 = phys(1);
         const float *__restrict__ pbase1 = in0 + (long)s1 * CKS * a.H * a.W;
         const float *__restrict__ abase1 = wp + (long)s1 * CKS * a.Mpad;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) load_patch_one(pregB, i, pbase1);
 #pragma unroll
         for (int i = 0; i < APER; ++i) load_a_one(aregB, i, abase1);
-        store_tiles(pregA, aregA, 0, okmask_of(s_begin));
+        store_tiles(pregA, aregA, 0, okmask_of(p0s));
     }
     __syncthreads();
     // during step s (buffer s&1): MFMAs on step s, loads of step s+2 into the set that step s freed, then the
     // set holding step s+1 goes to LDS buffer (s+1)&1.  Pairs of steps keep the set indices static.
     int s = 0;
     for (; s + 2 < nsteps; s += 2) {
-        kstep(0, clampstep(s_begin + s + 2), pregA, aregA, std::true_type{});
-        store_tiles(pregB, aregB, 1, okmask_of(s_begin + s + 1));
+        kstep(0, phys(s + 2), pregA, aregA, std::true_type{});
+        store_tiles(pregB, aregB, 1, okmask_of(phys(s + 1)));
         __syncthreads();
-        kstep(1, clampstep(s_begin + s + 3), pregB, aregB, std::true_type{});
-        store_tiles(pregA, aregA, 0, okmask_of(s_begin + s + 2));
+        kstep(1, phys(s + 3), pregB, aregB, std::true_type{});
+        store_tiles(pregA, aregA, 0, okmask_of(phys(s + 2)));
         __syncthreads();
     }
     if (s + 1 < nsteps) {
         kstep(0, 0, pregA, aregA, std::false_type{});
-        store_tiles(pregB, aregB, 1, okmask_of(s_begin + s + 1));
+        store_tiles(pregB, aregB, 1, okmask_of(phys(s + 1)));
         __syncthreads();
         ++s;
     }
     if (nsteps > 0) kstep(s & 1, 0, pregA, aregA, std::false_type{});
 
+#endif
     // ---- epilogue
     const int opy = cls >> 1, opx = cls & 1;
     const long plane = (long)a.Ho * a.Wo;
