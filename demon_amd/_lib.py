@@ -42,6 +42,9 @@ SIGNATURES = {
     "demon_set_weights_blob_device": (_I, [_P, _P, ctypes.c_int64]),
     "demon_set_option": (_I, [_P, ctypes.c_char_p, _I]),
     "demon_autotune": (_I, [_P, _I]),
+    "demon_num_layers": (_I, [_P]),
+    "demon_plan_get": (_I, [_P, _I, _I, ctypes.c_char_p, _I, c_int_p, c_int_p, c_int_p]),
+    "demon_plan_set": (_I, [_P, _I, ctypes.c_char_p, _I, _I, _I]),
     "demon_bootstrap": (_I, [_P, _I, c_float_p, c_float_p, ctypes.POINTER(DemonOutputs)]),
     "demon_iterative": (_I, [_P, _I, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                              ctypes.POINTER(DemonOutputs)]),

@@ -962,6 +962,37 @@ int demon_autotune(demon_ctx *c, int n)
     return DEMON_OK;
 }
 
+int demon_num_layers(const demon_ctx *c) { return c ? (int)c->layers.size() : 0; }
+
+int demon_plan_get(const demon_ctx *c, int n, int layer_index, char *name, int name_cap, int *kind, int *tile, int *ksplit)
+{
+    if (!c || layer_index < 0 || layer_index >= (int)c->layers.size()) return DEMON_ERR_INVALID;
+    const Layer *L = c->layers[layer_index].get();
+    if (name && name_cap > 0) { strncpy(name, L->name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    auto it = L->tuned.find(n);
+    if (it == L->tuned.end()) return DEMON_ERR_NOT_FOUND;
+    if (kind) *kind = it->second.kind;
+    if (tile) *tile = it->second.tile;
+    if (ksplit) *ksplit = it->second.ksplit;
+    return DEMON_OK;
+}
+
+int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int tile, int ksplit)
+{
+    if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (kind < 0 || kind > 1 || tile < 0 || tile >= (kind ? (int)PTILE_COUNT : (int)TILE_COUNT) || ksplit < 0)
+        return fail(c, DEMON_ERR_INVALID, "bad plan entry");
+    for (auto &L : c->layers)
+        if (L->name == layer_name) {
+            if (kind == 0 && L->Mpad % conv_tile_bm(tile)) return fail(c, DEMON_ERR_INVALID, "tile does not divide Cout");
+            for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+            c->graphs.clear();
+            L->tuned[n] = Layer::Tuned{kind, tile, kind == 0 && ksplit < 1 ? 1 : ksplit};
+            return DEMON_OK;
+        }
+    return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown layer ") + layer_name);
+}
+
 int demon_upload_inputs(demon_ctx *c, int n, const float *image_pair, const float *image2_2)
 {
     int r = check_batch(c, n);

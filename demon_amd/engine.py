@@ -88,6 +88,33 @@ class DemonContext:
         """measure every kernel variant per layer at batch n and keep the fastest (launch plans only)"""
         self._check(self.lib.demon_autotune(self.h, int(n)))
 
+    def get_plan(self, n):
+        """{layer name: [kind, tile, ksplit]} of the layers that have a tuned plan for batch n"""
+        out = {}
+        name = ctypes.create_string_buffer(128)
+        kind, tile, ks = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        for i in range(self.lib.demon_num_layers(self.h)):
+            rc = self.lib.demon_plan_get(self.h, int(n), i, name, 128, ctypes.byref(kind), ctypes.byref(tile), ctypes.byref(ks))
+            if rc == 0:
+                out[name.value.decode()] = [kind.value, tile.value, ks.value]
+        return out
+
+    def set_plan(self, n, plan):
+        for layer, (kind, tile, ks) in plan.items():
+            self._check(self.lib.demon_plan_set(self.h, int(n), layer.encode(), int(kind), int(tile), int(ks)))
+
+    def load_tuned_plan(self, n, directory=None):
+        """installs demon_amd/tuned/plan_<H>x<W>_n<n>.json if it exists; returns True when a plan was loaded"""
+        import json
+        import os
+        directory = directory or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
+        path = os.path.join(directory, "plan_%dx%d_n%d.json" % (self.H, self.W, int(n)))
+        if not os.path.exists(path):
+            return False
+        with open(path) as f:
+            self.set_plan(n, json.load(f)["plan"])
+        return True
+
     def set_option(self, key, value):
         self._check(self.lib.demon_set_option(self.h, key.encode(), int(value)))
 

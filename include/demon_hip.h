@@ -77,6 +77,11 @@ int demon_set_option(demon_ctx *ctx, const char *key, int value);
 /* Times every applicable kernel variant (im2col / patch-staged, tile shape, split-K) of every layer at batch n on
  * this GPU and keeps the fastest per layer (~1 s; results do not change, only launch plans). */
 int demon_autotune(demon_ctx *ctx, int n);
+/* read back / install launch plans (kind 0 = im2col kernel, 1 = patch-staged kernel; tile id; split-K), e.g. to ship
+ * the result of one autotune run as a file.  demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
+int demon_num_layers(const demon_ctx *ctx);
+int demon_plan_get(const demon_ctx *ctx, int n, int layer_index, char *name, int name_cap, int *kind, int *tile, int *ksplit);
+int demon_plan_set(demon_ctx *ctx, int n, const char *layer_name, int kind, int tile, int ksplit);
 
 /* ---- networks, host buffers in / host buffers out ------------------------------------------------
  * demon_bootstrap  replaces BootstrapNet.eval   (networks_original.py:60-88)

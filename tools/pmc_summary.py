@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 PMC passes of `bench.py` into profiles/<tag>_pmc_summary.json.
+
+  python tools/pmc_summary.py <tag> <fetch_dir> <write_dir> <mfma_dir>
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE counts wide coalesced reads at half
+their bytes (MI355X_MICROARCH.md, section HBM): the read side is doubled here, the write side is left as reported
+(uncalibrated).  Counters are collected in separate passes, as the guide prescribes.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+
+def load(d):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    with open(os.path.join(d, "p_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            name = r["Kernel_Name"]
+            fam = "conv" if ("conv_mfma_kernel" in name or "conv_patch_kernel" in name) else name.split("(")[0].replace("demon::", "")
+            agg[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    tag, fdir, wdir, mdir = sys.argv[1:5]
+    fetch, write, mfma = load(fdir), load(wdir), load(mdir)
+    out = {}
+    for fam in sorted(fetch):
+        fv = fetch[fam].get("FETCH_SIZE", [])
+        wv = write.get(fam, {}).get("WRITE_SIZE", [])
+        e = {"launches_sampled": len(fv)}
+        if fv:
+            e["fetch_bytes_per_launch_reported"] = 1024.0 * sum(fv) / len(fv)
+            e["fetch_bytes_per_launch_corrected_x2"] = 2048.0 * sum(fv) / len(fv)
+        if wv:
+            e["write_bytes_per_launch_reported"] = 1024.0 * sum(wv) / len(wv)
+        m = mfma.get(fam, {})
+        if m.get("SQ_VALU_MFMA_BUSY_CYCLES") and m.get("GRBM_GUI_ACTIVE"):
+            busy = sum(m["SQ_VALU_MFMA_BUSY_CYCLES"])
+            act = sum(m["GRBM_GUI_ACTIVE"]) / 8.0  # summed over the 8 XCDs
+            e["mfma_busy_frac"] = busy / (act * 1024.0)  # 256 CUs x 4 SIMDs
+        out[fam] = e
+    c = out.get("conv", {})
+    if "fetch_bytes_per_launch_corrected_x2" in c:
+        c["hbm_traffic_bytes_per_launch"] = c["fetch_bytes_per_launch_corrected_x2"] + c.get("write_bytes_per_launch_reported", 0.0)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", tag + "_pmc_summary.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(json.dumps(out.get("conv", {}), indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Autotunes the launch plan (kernel family / tile / split-K per layer) for one workload on the attached MI355X and
+writes it to <outdir>/plan_<H>x<W>_n<N>.json (copy into demon_amd/tuned/ to ship it).
+usage: python tools/tune.py --height 192 --width 256 --batch 32 [--rounds 3] [--outdir gpurun_out]"""
+import argparse, collections, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from demon_amd import DemonContext  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--height", type=int, default=192)
+ap.add_argument("--width", type=int, default=256)
+ap.add_argument("--batch", type=int, nargs="+", default=[32])
+ap.add_argument("--rounds", type=int, default=3, help="majority vote over this many autotune runs")
+ap.add_argument("--outdir", default="gpurun_out")
+args = ap.parse_args()
+os.makedirs(args.outdir, exist_ok=True)
+for n in args.batch:
+    ctx = DemonContext(0, n, args.height, args.width)
+    votes = collections.defaultdict(collections.Counter)
+    for _ in range(args.rounds):
+        ctx.autotune(n)
+        for layer, p in ctx.get_plan(n).items():
+            votes[layer][tuple(p)] += 1
+    plan = {layer: list(c.most_common(1)[0][0]) for layer, c in votes.items()}
+    path = os.path.join(args.outdir, "plan_%dx%d_n%d.json" % (args.height, args.width, n))
+    with open(path, "w") as f:
+        json.dump({"gpu": "MI355X (gfx950)", "height": args.height, "width": args.width, "batch": n, "plan": plan}, f, indent=0, sort_keys=True)
+    print(path, len(plan), "layers")
+    ctx.close()
