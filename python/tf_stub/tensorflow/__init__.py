@@ -1,0 +1,84 @@
+"""Minimal stand-in for the handful of TensorFlow-1 symbols that the reference driver examples/example.py touches
+(:45, :70-72, :79, :82-83), so that the unmodified script runs on the MI355X-native path without TensorFlow:
+
+    PYTHONPATH=<repo>/python/tf_stub:<repo>/python  MPLBACKEND=Agg  python <reference>/examples/example.py
+
+Put this directory on sys.path ONLY when the real tensorflow is absent.  Nothing here computes anything: the networks
+(depthmotionnet.networks_original) run on libdemon_hip.so; `tf.train.Saver().restore` reads the reference's TensorBundle
+checkpoint with demon_amd.tf_checkpoint (or a .npz written by demon_amd.weights.save_npz).
+"""
+import os
+
+__version__ = "1.4.0-demon-amd-stub"
+
+
+class _Test:
+    @staticmethod
+    def is_gpu_available(cuda_only=False):
+        import ctypes
+        try:
+            from demon_amd import _lib
+            _lib.load()
+            import torch  # device query only
+            return bool(torch.cuda.is_available())
+        except Exception:
+            return False
+
+
+test = _Test()
+
+
+class GPUOptions:
+    per_process_gpu_memory_fraction = 1.0
+
+
+class ConfigProto:
+    def __init__(self, allow_soft_placement=False, gpu_options=None, **kwargs):
+        self.allow_soft_placement = allow_soft_placement
+        self.gpu_options = gpu_options
+
+
+class InteractiveSession:
+    """holds the weights for the network classes (they read `session.demon_weights`)"""
+
+    def __init__(self, config=None, **kwargs):
+        self.config = config
+        self.demon_weights = None
+
+    def run(self, fetches=None, feed_dict=None):
+        return None  # only ever called with global_variables_initializer() by the example
+
+    def close(self):
+        pass
+
+
+Session = InteractiveSession
+
+
+def global_variables_initializer():
+    return None
+
+
+class _Saver:
+    def restore(self, session, save_path):
+        import demon_amd
+        from demon_amd import weights as W
+        names = list(W.variable_shapes())
+        if os.path.exists(save_path + ".index"):
+            from demon_amd.tf_checkpoint import load_tf_checkpoint
+            w = load_tf_checkpoint(save_path, names)
+        elif os.path.exists(save_path + ".npz"):
+            w = W.load_npz(save_path + ".npz")
+        elif os.environ.get("DEMON_SYNTHETIC_WEIGHTS") == "1":
+            w = W.synthetic_weights(seed=1)
+        else:
+            raise IOError("checkpoint %s(.index|.npz) not found (set DEMON_SYNTHETIC_WEIGHTS=1 for random weights)" % save_path)
+        session.demon_weights = w
+        demon_amd.set_default_weights(w)  # networks constructed before restore() pick the weights up here
+
+
+class _Train:
+    Saver = _Saver
+
+
+train = _Train()

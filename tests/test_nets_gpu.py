@@ -1,6 +1,7 @@
 """GPU parity of the three networks and the device-resident full pipeline against the CPU oracle on the
 same seeded inputs and weights, through the C ABI.  Gate: relative L1 <= 1e-3 per output tensor
 (BASELINE.json north_star); typical observed values are ~1e-6..1e-5 (summation order only)."""
+import os
 import numpy as np
 import pytest
 
@@ -178,3 +179,26 @@ def test_autotune_keeps_results(gpu_ctx, ref):
     _cmp(after, want, KEYS + ("predict_depth0",))
     for k in KEYS + ("predict_depth0",):
         assert rel_l1(after[k], before[k]) < 1e-4, k
+
+
+def test_example_script_runs_on_an_image_pair(tmp_path, synth_weights):
+    """examples/example.py (the reference driver's flow) end to end: PNGs -> depth / motion, weights from a TensorBundle
+    checkpoint written in the reference's own format"""
+    import subprocess
+    import sys
+    from PIL import Image
+    from demon_amd import tf_checkpoint as ck
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    rng = np.random.default_rng(40)
+    base = rng.integers(0, 255, (192 + 8, 256 + 8, 3), dtype=np.uint8)
+    Image.fromarray(base[:192, :256]).save(tmp_path / "a.png")
+    Image.fromarray(base[4:196, 6:262]).save(tmp_path / "b.png")
+    prefix = str(tmp_path / "weights" / "demon_original")
+    ck.save_tf_checkpoint(prefix, synth_weights)
+    out = str(tmp_path / "result.npz")
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "example.py"), str(tmp_path / "a.png"), str(tmp_path / "b.png"),
+                        "--weights", prefix, "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = np.load(out)
+    assert res["predict_depth0"].shape == (1, 1, 192, 256) and np.isfinite(res["predict_depth0"]).all()
+    assert res["rotation"].shape == (1, 3) and res["translation"].shape == (1, 3)
