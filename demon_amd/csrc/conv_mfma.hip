@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     }
     // ---- epilogue: bias, leaky relu, optional per-sample scale of channel 0, coalesced NCHW store
     const int pyc = cls >> 1, pxc = cls & 1;  // cls = 0 for plain convs
-    const long plane = (long)a.Ho * a.Wo;
+    const long plane = a.out_plane;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const long p = p0 + (wn * TN + j) * 32 + l31;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a)
     const int y = (int)(t % a.Hp);
     const int n = (int)(t / a.Hp);
     if (co == 0 && a.scale) v *= a.scale[n];
-    a.out[(long)n * a.out_n_stride + (long)co * a.Ho * a.Wo + (long)(y * a.osy + (cls >> 1)) * a.Wo + (x * a.osx + (cls & 1))] = v;
+    a.out[(long)n * a.out_n_stride + (long)co * a.out_plane + (long)(y * a.osy + (cls >> 1)) * a.Wo + (x * a.osx + (cls & 1))] = v;
 }
 
 struct TileInfo { int bm, bn, threads; float eff; };

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 
 // ---- host side --------------------------------------------------------------------------------------
 struct PatchTile { int bm, bn, threads; };
-static const PatchTile kPatchTiles[PTILE_COUNT] = {{128, 128, 256}, {64, 128, 256}, {32, 128, 256}, {64, 64, 256}};
+static const PatchTile kPatchTiles[PTILE_COUNT] = {{128, 128, 256}, {64, 128, 256}, {32, 128, 256}, {64, 64, 256}, {128, 64, 256}, {32, 64, 128}};
 
 int patch_cks(int ntaps)
 {
@@ -340,6 +340,7 @@ int patch_cks(int ntaps)
 
 int patch_tile_bm(int tile) { return kPatchTiles[tile].bm; }
 int patch_tile_bn(int tile) { return kPatchTiles[tile].bn; }
+int patch_tile_threads(int tile) { return kPatchTiles[tile].threads; }
 
 size_t patch_lds_bytes(int tile, int ntaps, int G, int PS)
 {
@@ -381,6 +382,8 @@ void launch_conv_patch(const PatchArgs &a, int tile, int ntaps, int nclasses, hi
         case PTILE_128x128: launch_patch_ept<128, 2, 2, 2, 2>(a, ntaps, grid, lds, stream); break;
         case PTILE_64x128:  launch_patch_ept<64, 2, 2, 1, 2>(a, ntaps, grid, lds, stream); break;
         case PTILE_32x128:  launch_patch_ept<32, 1, 4, 1, 1>(a, ntaps, grid, lds, stream); break;
+        case PTILE_128x64:  launch_patch_ept<128, 2, 2, 2, 1>(a, ntaps, grid, lds, stream); break;
+        case PTILE_32x64:   launch_patch_ept<32, 1, 2, 1, 1>(a, ntaps, grid, lds, stream); break;
         default:            launch_patch_ept<64, 2, 2, 1, 1>(a, ntaps, grid, lds, stream); break;
     }
 }

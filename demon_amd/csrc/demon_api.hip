@@ -37,6 +37,7 @@ struct Layer {
     bool have_kernel = false, have_bias = false;
     std::vector<int64_t> kernel_dims;  // TF layout
     int force_tile = -1, force_split = 0;  // tuning override (demon_bench_layer)
+    int plane_pad = 0;                     // experiment: extra floats between channel planes of in / out
     // autotuned choice per batch size: kind 0 = im2col kernel (tile, ksplit), 1 = patch kernel (patch tile)
     struct Tuned { int kind, tile, ksplit; };
     std::map<int, Tuned> tuned;
@@ -164,7 +165,7 @@ bool plan_layer(demon_ctx *c, Layer *L)
                 for (int ci = 0; ci < L->Cin; ++ci) {
                     const int k = (a * L->kw + b) * L->Cin + ci;
                     const int dy = a - L->ph, dx = b - L->pw;
-                    tab[k] = KEntry{ci * H * W + dy * W + dx, pack(dy, dx)};
+                    tab[k] = KEntry{ci * (H * W + L->plane_pad) + dy * W + dx, pack(dy, dx)};
                 }
     } else if (L->kind == Layer::DECONV) {
         // output (2y+py, 2x+px) of the cropped k4 s2 transposed conv reads input rows
@@ -177,7 +178,7 @@ bool plan_layer(demon_ctx *c, Layer *L)
                     for (int ci = 0; ci < L->Cin; ++ci) {
                         const int k = (ty * 2 + tx) * L->Cin + ci;
                         const int dy = tap_d[py][ty], dx = tap_d[px][tx];
-                        tab[(size_t)cls * L->Kpad + k] = KEntry{ci * H * W + dy * W + dx, pack(dy, dx)};
+                        tab[(size_t)cls * L->Kpad + k] = KEntry{ci * (H * W + L->plane_pad) + dy * W + dx, pack(dy, dx)};
                     }
         }
     } else {
@@ -242,7 +243,9 @@ void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
     a.Kpad = L->Kpad;
     a.Ho = L->out.H;
     a.Wo = L->out.W;
-    a.out_n_stride = L->out.n_stride();
+    a.out_n_stride = L->out.n_stride() + (long)L->plane_pad * L->out.Ctot;
+    a.in_n_stride += (long)L->plane_pad * L->in.Ctot;
+    a.out_plane = (long)L->out.H * L->out.W + L->plane_pad;
     a.act = L->act;
     a.cls_w_stride = (long)L->Krows * L->Mpad;
     a.ksplit = 1;
@@ -276,7 +279,7 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
     float best_cost = 1e30f;
     for (int tile = 0; tile < PTILE_COUNT; ++tile) {
         if (only_tile >= 0 && tile != only_tile) continue;
-        const int bm = patch_tile_bm(tile), bn = patch_tile_bn(tile), nt = 256;
+        const int bm = patch_tile_bm(tile), bn = patch_tile_bn(tile), nt = patch_tile_threads(tile);
         if (L->Mpad % bm) continue;
         for (int tw_sel = 0; tw_sel < 4; ++tw_sel) {
             int TW = tw_sel == 0 ? (Wp < bn ? Wp : bn) : (bn >> tw_sel);  // Wp/bn, bn/2, bn/4, bn/8
@@ -388,7 +391,11 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             const Layer::Tuned &t = it->second;
             if (t.kind == 1) {
                 PatchPlan pp;
-                if (plan_patch(L, n, ws, pp, t.tile)) { launch_patch_plan(L, pp, a, P, ws, s); return; }
+                if (plan_patch(L, n, ws, pp, t.tile)) {
+                    if (t.ksplit > 0) pp.a.ksplit = t.ksplit < pp.a.nsteps_total ? t.ksplit : pp.a.nsteps_total;
+                    launch_patch_plan(L, pp, a, P, ws, s);
+                    return;
+                }
             } else {
                 launch_conv_mfma(a, ConvPlan{t.tile, clamp_split(t.ksplit)}, L->ncls, s);
                 return;
@@ -432,7 +439,16 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
     }
     for (int t = 0; t < PTILE_COUNT; ++t) {
         PatchPlan pp;
-        if (plan_patch(L, n, c->d_ws, pp, t)) cands.push_back({1, t, 0});
+        if (!plan_patch(L, n, c->d_ws, pp, t)) continue;
+        cands.push_back({1, t, 0});  // 0 = the planner's own split-K
+        const long groups = (n + pp.a.G - 1) / pp.a.G;
+        const long wgs = groups * pp.a.tiles_y * pp.a.tiles_x * (L->Mpad / patch_tile_bm(t)) * L->ncls;
+        for (int ks : {1, 2, 3, 4, 6, 8}) {
+            if (ks == pp.a.ksplit || ks > pp.a.nsteps_total / 2 || wgs * ks > 2048) continue;
+            if (ks > 1 && (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats) continue;
+            if (wgs * ks < 96) continue;
+            cands.push_back({1, t, ks});
+        }
     }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;

@@ -58,6 +58,7 @@ struct ConvArgs {
     float *ws;          // split-K workspace [cls][slice][Mpad][P]
     int ksplit;         // number of K slices (1 = fused epilogue)
     int dbg;            // ablation switches for tuning experiments (0 in production)
+    long out_plane;     // elements between output channel planes (Ho*Wo unless the buffer is padded)
 };
 
 enum ConvTile { TILE_128x128 = 0, TILE_64x128, TILE_32x128, TILE_64x64, TILE_32x64, TILE_32x32, TILE_128x32, TILE_64x32, TILE_COUNT };
@@ -94,10 +95,11 @@ struct PatchArgs {
     int osy, osx;
     int act, ksplit, nsteps_total;
 };
-enum PatchTileId { PTILE_128x128 = 0, PTILE_64x128, PTILE_32x128, PTILE_64x64, PTILE_COUNT };
+enum PatchTileId { PTILE_128x128 = 0, PTILE_64x128, PTILE_32x128, PTILE_64x64, PTILE_128x64, PTILE_32x64, PTILE_COUNT };
 int patch_cks(int ntaps);
 int patch_tile_bm(int tile);
 int patch_tile_bn(int tile);
+int patch_tile_threads(int tile);
 size_t patch_lds_bytes(int tile, int ntaps, int G, int PS);
 void launch_conv_patch(const PatchArgs &a, int tile, int ntaps, int nclasses, hipStream_t stream);
 

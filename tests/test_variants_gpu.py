@@ -44,7 +44,7 @@ def test_all_variants_agree(gpu_ctx, layer):
         w = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
     b = rng.standard_normal((cout,)).astype(np.float32)
     want = _ref(kind, x, w, b, (sh, sw))
-    plans = [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(4) for ks in (0, 2, 3, 5)]
+    plans = [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(6) for ks in (0, 2, 3, 5)]
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan

@@ -43,19 +43,32 @@ __global__ __launch_bounds__(256) void probe(const float *__restrict__ A, const 
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
-            if (V >= 4) {
+            if (V == 4) {
                 breg[g] = bp[(size_t)(s & 63) * 256 + g * 32768];
                 if (g < 2) areg[g] = *reinterpret_cast<const floatx4 *>(ap + (size_t)(s & 63) * 1024 + g * 65536);
             }
+            if (V == 5) {
+                const int wave = tid >> 6;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bp + (size_t)(s & 63) * 256 + g * 32768),
+                                                 (__attribute__((address_space(3))) void *)(&Bs[buf ^ 1][(tid >> 7) * 8 + g][(wave & 1) * 64]), 4, 0, 0);
+                if (g < 2)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ap + (size_t)(s & 63) * 1024 + g * 65536),
+                                                     (__attribute__((address_space(3))) void *)(&As[buf ^ 1][g * 8 + wave * 2][0]), 16, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (V >= 3) {
+        if (V == 5) {
+            // direct-to-LDS DMA: destination = wave-uniform base + lane * size
+            __shared__ int dummy_guard;
+            (void)dummy_guard;
+        }
+        if (V >= 3 && V != 5) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) Bs[buf ^ 1][(tid >> 7) * 8 + i][tid & 127] = breg[i] + (V >= 4 ? 0.f : (float)s);
 #pragma unroll
             for (int i = 0; i < 2; ++i) *reinterpret_cast<floatx4 *>(&As[buf ^ 1][(tid >> 5) + i * 8][(tid & 31) * 4]) = areg[i];
         }
-        if (V >= 2) __syncthreads();
+        if (V >= 2) __syncthreads();  // V5: the barrier's vmcnt(0) also drains the DMA
     }
     float sum = 0;
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
@@ -94,6 +107,7 @@ int main()
         run<2>(A, B, out, wgs, 72, "+ barrier every step");
         run<3>(A, B, out, wgs, 72, "+ LDS tile writes every step");
         run<4>(A, B, out, wgs, 72, "+ global loads interleaved (8 dword + 2 dwordx4)");
+        run<5>(A, B, out, wgs, 72, "same loads as direct-to-LDS DMA, no ds_write");
     }
     for (int wgs : {256, 512, 768, 1024, 1536})
         for (int ns : {18, 72, 288}) { char b[64]; snprintf(b, 64, "pure MFMA nsteps=%d", ns); run<0>(A, B, out, wgs, ns, b); }
