@@ -114,25 +114,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     // (~2300+ cycles) to return before anybody waits for it
     float pregA[EPT], pregB[EPT];
     floatx4 aregA[APER], aregB[APER];
-#if defined(ABL_NOLOAD) || defined(ABL_NOLOAD_P)
-    auto load_patch_one = [&](float (&preg)[EPT], int i, const float *__restrict__ base) { preg[i] = (float)i; };
-#else
     auto load_patch_one = [&](float (&preg)[EPT], int i, const float *__restrict__ base) {
         // only real elements: a dummy load of one shared address from every wave of every workgroup is an L2 hot spot
         if ((wrbits >> i) & 1u) preg[i] = base[goff[i]];
     };
-#endif
     auto load_a_one = [&](floatx4 (&areg)[APER], int i, const float *__restrict__ base) {
-#if defined(ABL_NOLOAD) || defined(ABL_NOLOAD_A)
-        areg[i] = floatx4{1.f, 2.f, 3.f, 4.f};
-#else
         if (A4 % NT == 0 || tid + i * NT < A4) areg[i] = *reinterpret_cast<const floatx4 *>(base + aoff[i]);
-#endif
     };
     auto store_tiles = [&](const float (&preg)[EPT], const floatx4 (&areg)[APER], int buf, unsigned ok) {
-#ifdef ABL_NOSTORE
-        return;
-#endif
         float *P = Ps + buf * patch_floats;
 #pragma unroll
         for (int i = 0; i < EPT; ++i)
@@ -152,22 +141,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
         for (int kk = 0; kk < NG; ++kk) {
             const int k = 2 * kk + lhi;
 #pragma unroll
-#ifdef ABL_NOFRAG
-            for (int i = 0; i < TM; ++i) av[kk][i] = (float)(k + i) + (float)buf;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[kk][j] = (float)(k - j) + (float)buf;
-#else
             for (int i = 0; i < TM; ++i) av[kk][i] = A[k * BM + (wm * TM + i) * 32 + l31];
 #pragma unroll
             for (int j = 0; j < TN; ++j) bv[kk][j] = *reinterpret_cast<const float *>(Pb + bbase[j] + so[kk]);
-#endif
         }
         const float *__restrict__ pbase = in0 + (long)next * CKS * a.H * a.W;
         const float *__restrict__ abase = wp + (long)next * CKS * a.Mpad;
         __builtin_amdgcn_sched_barrier(0);
-#ifdef USE_SETPRIO
-        __builtin_amdgcn_s_setprio(USE_SETPRIO);
-#endif
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -186,62 +166,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifdef USE_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     };
 
-#ifdef START_SKEW
-    {   // phase-shift the (up to 3) workgroups that share a CU so that their load / store / barrier sections do not coincide
-        const int ph = (blockIdx.x / 256) % 3;
-        for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(START_SKEW);
-    }
-#endif
-#ifdef STATIC_PRIO
-    {   // distinct static priorities for the (up to 3) workgroups sharing a CU: the co-resident waves of a SIMD
-        // then stop marching in lock step (block b -> XCD b%8, CU (b/8)%32; b/256 separates co-residents)
-        const int pr = (blockIdx.x / STATIC_PRIO) % 3;
-        if (pr == 1) __builtin_amdgcn_s_setprio(1);
-        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-    }
-#endif
     const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
     const int s_begin = zs * per_slice;
     const int nsteps = min(a.nsteps_total, s_begin + per_slice) - s_begin;
     auto okmask_of = [&](int step) { return step == a.nsteps_total - 1 ? oklast : okbits; };
-    // optional K rotation (-DK_ROTATE): workgroup b starts at channel chunk (b mod nsteps) so that the workgroups of one
-    // Cout tile do not all read the same weight rows at the same time.  Measured: no gain on MI355X, off by default.
-#ifndef K_ROTATE
-    const int rot = 0;
-#else
-    const int rot = nsteps > 0 ? (int)((blockIdx.x * 5u + blockIdx.y * 3u) % (unsigned)nsteps) : 0;
-#endif
-    auto phys = [&](int x) {  // logical step of this slice -> chunk index; run-ahead past the end re-reads the last one
-        x = min(x, nsteps - 1);
-        int r = x + rot;
-        if (r >= nsteps) r -= nsteps;
-        return s_begin + r;
-    };
-#ifdef PREFETCH_DIST1
-    if (nsteps > 0) {
-        const int p0s = phys(0);
-        const float *__restrict__ pbase = in0 + (long)p0s * CKS * a.H * a.W;
-        const float *__restrict__ abase = wp + (long)p0s * CKS * a.Mpad;
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) load_patch_one(pregA, i, pbase);
-#pragma unroll
-        for (int i = 0; i < APER; ++i) load_a_one(aregA, i, abase);
-        store_tiles(pregA, aregA, 0, okmask_of(p0s));
-    }
-    __syncthreads();
-    for (int s = 0; s + 1 < nsteps; ++s) {
-        kstep(s & 1, phys(s + 1), pregA, aregA, std::true_type{});
-        store_tiles(pregA, aregA, (s & 1) ^ 1, okmask_of(phys(s + 1)));
-        __syncthreads();
-    }
-    if (nsteps > 0) kstep((nsteps - 1) & 1, 0, pregA, aregA, std::false_type{});
-    (void)pregB; (void)aregB;
-#else
+    auto phys = [&](int x) { return s_begin + min(x, nsteps - 1); };  // step of this K slice; a run-ahead past the end re-reads the last one
     if (nsteps > 0) {
         // prologue: step 0 -> LDS buffer 0; step 1 -> register set B (stored at the end of step 0)
         const int p0s = phys(0);
@@ -280,7 +211,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     }
     if (nsteps > 0) kstep(s & 1, 0, pregA, aregA, std::false_type{});
 
-#endif
     // ---- epilogue
     const int opy = cls >> 1, opx = cls & 1;
     const long plane = (long)a.Ho * a.Wo;
