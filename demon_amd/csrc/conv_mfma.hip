@@ -233,6 +233,53 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     // ---- epilogue: bias, leaky relu, optional per-sample scale of channel 0, coalesced NCHW store
     const int pyc = cls >> 1, pxc = cls & 1;  // cls = 0 for plain convs
     const long plane = a.out_plane;
+    // Fast path (plain convs, image rows a multiple of 4 pixels, all channels real): 4x4 transpose inside every lane quad
+    // (two DPP butterfly stages) so that each lane stores 4 consecutive pixels of one channel with one 16-byte store
+    if (a.osx == 1 && a.osy == 1 && (a.Wp & 3) == 0 && (a.Cout & 3) == 0 && a.scale == nullptr) {
+        const int q = l31 >> 2, li = lane & 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long p = p0 + (wn * TN + j) * 32 + 4 * q;
+            const bool ok = p < P;
+            const long pc = ok ? p : 0;
+            const int x = (int)(pc % a.Wp);
+            const long t = pc / a.Wp;
+            const int y = (int)(t % a.Hp);
+            const int n = (int)(t / a.Hp);
+            float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)y * a.Wo + x;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    float v0 = acc[i][j][4 * rb + 0], v1 = acc[i][j][4 * rb + 1], v2 = acc[i][j][4 * rb + 2], v3 = acc[i][j][4 * rb + 3];
+                    {
+                        const bool odd = li & 1;  // exchange with the lane at distance 1 (quad_perm [1,0,3,2])
+                        float s0 = odd ? v0 : v1, s1 = odd ? v2 : v3;
+                        s0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+                        s1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+                        if (odd) { v0 = s0; v2 = s1; } else { v1 = s0; v3 = s1; }
+                    }
+                    {
+                        const bool hi = li & 2;  // exchange with the lane at distance 2 (quad_perm [2,3,0,1])
+                        float s0 = hi ? v0 : v2, s1 = hi ? v1 : v3;
+                        s0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
+                        s1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
+                        if (hi) { v0 = s0; v1 = s1; } else { v2 = s0; v3 = s1; }
+                    }
+                    const int co = m0 + (wm * TM + i) * 32 + li + 8 * rb + 4 * lhi;
+                    if (ok && co < a.Cout) {
+                        const float b = a.bias[co];
+                        floatx4 v = {v0 + b, v1 + b, v2 + b, v3 + b};
+                        if (a.act) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : 0.1f * v[e];
+                        }
+                        *reinterpret_cast<floatx4 *>(ob + (long)co * plane) = v;
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const long p = p0 + (wn * TN + j) * 32 + l31;

@@ -215,6 +215,59 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     const int opy = cls >> 1, opx = cls & 1;
     const long plane = (long)a.Ho * a.Wo;
     const long Ptot = (long)a.N * a.Hp * a.Wp;
+    // Fast path (plain convs whose tile rows and image rows are multiples of 4 pixels, all channels real): a 4x4
+    // transpose inside every lane quad (two DPP butterfly stages) turns "lane = 1 pixel x 4 consecutive channels" into
+    // "lane = 4 consecutive pixels x 1 channel", so each accumulator block leaves as ONE 16-byte store per lane
+    // instead of four 4-byte stores (the store tail of a one-round grid is issue bound).
+    const bool wide = a.ksplit == 1 && a.osx == 1 && a.osy == 1 && (a.TW & 3) == 0 && (a.Wp & 3) == 0 && (a.Cout & 3) == 0 && a.scale == nullptr;
+    if (wide) {
+        const int q = l31 >> 2, li = lane & 3;  // quad index inside the half wave, lane inside the quad
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int pj = (wn * TN + j) * 32 + 4 * q;  // first of this lane's 4 pixels
+            const bool pv = pj < tile_pixels;
+            const int pjc = pv ? pj : 0;
+            const int g = pjc / (a.TH * a.TW), rem = pjc - g * (a.TH * a.TW);
+            const int py = rem / a.TW, px = rem - py * a.TW;
+            const int y = ty * a.TH + py, x = tx * a.TW + px, n = n0 + g;
+            const bool ok = pv && y < a.Hp && x < a.Wp && n < a.N;
+            float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)y * a.Wo + x;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    float v0 = acc[i][j][4 * rb + 0], v1 = acc[i][j][4 * rb + 1], v2 = acc[i][j][4 * rb + 2], v3 = acc[i][j][4 * rb + 3];
+                    // stage 1: exchange with the lane at distance 1 (quad_perm [1,0,3,2])
+                    {
+                        const bool odd = li & 1;
+                        float s0 = odd ? v0 : v1, s1 = odd ? v2 : v3;
+                        s0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+                        s1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+                        if (odd) { v0 = s0; v2 = s1; } else { v1 = s0; v3 = s1; }
+                    }
+                    // stage 2: exchange with the lane at distance 2 (quad_perm [2,3,0,1])
+                    {
+                        const bool hi = li & 2;
+                        float s0 = hi ? v0 : v2, s1 = hi ? v1 : v3;
+                        s0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
+                        s1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
+                        if (hi) { v0 = s0; v1 = s1; } else { v2 = s0; v3 = s1; }
+                    }
+                    // now this lane holds channel (row block + li) for pixels 4q .. 4q+3
+                    const int co = m0 + (wm * TM + i) * 32 + li + 8 * rb + 4 * lhi;
+                    if (ok && co < a.Cout) {
+                        const float b = a.bias[co];
+                        floatx4 v = {v0 + b, v1 + b, v2 + b, v3 + b};
+                        if (a.act) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : 0.1f * v[e];
+                        }
+                        *reinterpret_cast<floatx4 *>(ob + (long)co * plane) = v;
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int pj = (wn * TN + j) * 32 + l31;
