@@ -11,6 +11,8 @@
 //   replace_nonfinite                v2/losses.py:49
 //   scale_invariant_gradient         v2/losses.py:76-79
 //   median3x3_downsample             examples/evaluation.py:173
+#include <stdlib.h>
+
 #include "internal.h"
 
 namespace demon {
@@ -180,9 +182,8 @@ __global__ __launch_bounds__(256) void flow_to_depth_kernel(float *__restrict__ 
     out[(long)n * out_n_stride + idx] = inverse_depth ? 1.0f / z : z;
 }
 
-// Backward bilinear warp.  grid: (ceil(H*W/256), N); each thread handles one pixel for all C channels.
-// The source planes of one sample are at most a few hundred KB (3 x 48 x 64 floats at level 2), i.e.
-// L1/L2 resident; the four taps of neighbouring lanes fall into the same or adjacent 128-byte lines.
+// Backward bilinear warp, direct gather (default, see launch_warp2d).  grid: (ceil(H*W/256), N); each thread handles one
+// pixel for all C channels; the four taps of neighbouring lanes fall into the same or adjacent 128-byte lines.
 __global__ __launch_bounds__(256) void warp2d_kernel(float *__restrict__ out, long out_n_stride,
                                                      const float *__restrict__ in, long in_n_stride,
                                                      const float *__restrict__ disp, long disp_n_stride, int C,
@@ -231,6 +232,87 @@ __global__ __launch_bounds__(256) void warp2d_kernel(float *__restrict__ out, lo
     }
 }
 
+// LDS-staged variant: a block owns a 4 x 64 output tile (one wavefront per 64-pixel row segment).  The block first
+// reduces the bounding box of all source taps it needs; when that box (tile + displacement halo) fits the LDS tile it
+// is copied once per channel with coalesced row loads and the four bilinear taps of every pixel are gathered from LDS;
+// otherwise (large or incoherent displacements) the block falls back to the direct global gather.
+// grid: (ceil(W/64), ceil(H/4), N)
+#define WARP_LDS_FLOATS 8192
+__global__ __launch_bounds__(256) void warp2d_lds_kernel(float *__restrict__ out, long out_n_stride,
+                                                         const float *__restrict__ in, long in_n_stride,
+                                                         const float *__restrict__ disp, long disp_n_stride, int C, int H,
+                                                         int W, int normalized, int border_mode, float border_value)
+{
+    __shared__ float tile[WARP_LDS_FLOATS];
+    __shared__ int bb[4];  // min x, max x, min y, max y of the (clamped) taps
+    const int n = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const bool inside = x < W && y < H;
+    const int hw = H * W;
+    const int idx = inside ? y * W + x : 0;
+    float dx = disp[(long)n * disp_n_stride + idx];
+    float dy = disp[(long)n * disp_n_stride + hw + idx];
+    if (normalized) { dx *= W; dy *= H; }
+    const float sx = x + dx, sy = y + dy;
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const float a = sx - fx0, b = sy - fy0;
+    const bool finite = isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
+    const int x0 = finite ? (int)fx0 : -2, y0 = finite ? (int)fy0 : -2;
+    const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
+    int xi[2] = {x0, x0 + 1}, yi[2] = {y0, y0 + 1};
+    bool okx[2], oky[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        okx[k] = xi[k] >= 0 && xi[k] < W;
+        oky[k] = yi[k] >= 0 && yi[k] < H;
+        xi[k] = min(max(xi[k], 0), W - 1);
+        yi[k] = min(max(yi[k], 0), H - 1);
+    }
+    if (threadIdx.x == 0) { bb[0] = W; bb[1] = -1; bb[2] = H; bb[3] = -1; }
+    __syncthreads();
+    if (inside && finite) {
+        atomicMin(&bb[0], xi[0]); atomicMax(&bb[1], xi[1]);
+        atomicMin(&bb[2], yi[0]); atomicMax(&bb[3], yi[1]);
+    }
+    __syncthreads();
+    const int bx0 = bb[0], bx1 = bb[1], by0 = bb[2], by1 = bb[3];
+    const int rw = bx1 - bx0 + 1, rh = by1 - by0 + 1;
+    const bool staged = rw > 0 && rh > 0 && (long)rw * rh <= WARP_LDS_FLOATS;
+    const bool value_mode = border_mode == 1;
+    for (int c = 0; c < C; ++c) {
+        const float *p = in + (long)n * in_n_stride + (long)c * hw;
+        float v[4];
+        if (staged) {
+            __syncthreads();  // previous channel's gathers are done
+            for (int e = threadIdx.x; e < rw * rh; e += 256) {
+                const int ry = e / rw, rx = e - ry * rw;
+                tile[e] = p[(by0 + ry) * W + bx0 + rx];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kx = k & 1, ky = k >> 1;
+                const float g = (inside && finite) ? tile[(yi[ky] - by0) * rw + (xi[kx] - bx0)] : 0.0f;
+                v[k] = (value_mode && !(finite && okx[kx] && oky[ky])) ? border_value : g;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kx = k & 1, ky = k >> 1;
+                const float g = p[yi[ky] * W + xi[kx]];
+                v[k] = (value_mode && !(finite && okx[kx] && oky[ky])) ? border_value : g;
+            }
+        }
+        float r;
+        if (finite)
+            r = w00 * v[0] + w01 * v[1] + w10 * v[2] + w11 * v[3];
+        else
+            r = value_mode ? border_value : __builtin_nanf("");
+        if (inside) out[(long)n * out_n_stride + (long)c * hw + idx] = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void leaky_relu_kernel(float *__restrict__ out, const float *__restrict__ in,
                                                          long count, float leak)
 {
@@ -267,24 +349,39 @@ __global__ __launch_bounds__(256) void replace_nonfinite_kernel(float *__restric
 // grid: (ceil(W/64), ceil(H/4), NC)
 #define SIG_MAX_DELTAS 8
 struct SigParams { int deltas[SIG_MAX_DELTAS]; float weights[SIG_MAX_DELTAS]; int n; };
+#define SIG_MAX_HALO 16
 __global__ __launch_bounds__(256) void sig_kernel(float *__restrict__ out, const float *__restrict__ in, int H, int W,
-                                                  SigParams sp, float eps)
+                                                  SigParams sp, float eps, int halo)
 {
+    // 4 x 64 tile plus `halo` = max |delta| pixels on every side, staged once; all neighbours come from LDS
+    __shared__ float tile[(4 + 2 * SIG_MAX_HALO) * (64 + 2 * SIG_MAX_HALO)];
     const int z = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 4;
     const float *p = in + (long)z * H * W;
-    const float u = p[y * W + x];
+    const bool staged = halo <= SIG_MAX_HALO;
+    const int tw = 64 + 2 * halo, th = 4 + 2 * halo;
+    if (staged) {
+        for (int e = threadIdx.x; e < tw * th; e += 256) {
+            const int ry = e / tw, rx = e - ry * tw;
+            const int gy = ty0 - halo + ry, gx = tx0 - halo + rx;
+            tile[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? p[gy * W + gx] : 0.0f;
+        }
+        __syncthreads();
+    }
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x >= W || y >= H) return;
+    auto at = [&](int yy, int xx) { return staged ? tile[(yy - ty0 + halo) * tw + (xx - tx0 + halo)] : p[yy * W + xx]; };
+    const float u = at(y, x);
     float gx = 0.0f, gy = 0.0f;
     for (int k = 0; k < sp.n; ++k) {
         const int d = sp.deltas[k];
         if (x + d >= 0 && x + d < W) {
-            const float un = p[y * W + x + d];
+            const float un = at(y, x + d);
             gx += sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
         }
         if (y + d >= 0 && y + d < H) {
-            const float un = p[(y + d) * W + x];
+            const float un = at(y + d, x);
             gy += sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
         }
     }
@@ -394,6 +491,17 @@ void launch_warp2d(float *out, long out_n_stride, const float *in, long in_n_str
                    long disp_n_stride, int N, int C, int H, int W, int normalized, int border_mode,
                    float border_value, hipStream_t s)
 {
+    // Measured on MI355X (640x480 level-2 maps, batch 64, the incoherent flow of random weights): direct gather 18-25 us,
+    // LDS-staged 82-100 us; at 48x64 both are launch bound.  The source planes (3 x 120 x 160 floats) are L1/L2 resident,
+    // so staging only pays for coherent flow on maps that do not cache-fit: direct gather is the default, DEMON_WARP_LDS=1
+    // selects the staged kernel (same results, covered by the tests).
+    static const bool use_lds = getenv("DEMON_WARP_LDS") && atoi(getenv("DEMON_WARP_LDS")) != 0;
+    if (use_lds) {
+        dim3 grid((W + 63) / 64, (H + 3) / 4, N);
+        hipLaunchKernelGGL(warp2d_lds_kernel, grid, dim3(256), 0, s, out, out_n_stride, in, in_n_stride, disp,
+                           disp_n_stride, C, H, W, normalized, border_mode, border_value);
+        return;
+    }
     dim3 grid((H * W + 255) / 256, N);
     hipLaunchKernelGGL(warp2d_kernel, grid, dim3(256), 0, s, out, out_n_stride, in, in_n_stride, disp, disp_n_stride, C,
                        H, W, normalized, border_mode, border_value);
@@ -418,7 +526,9 @@ void launch_sig(float *out, const float *in, int NC, int H, int W, const int *de
     sp.n = ndeltas;
     for (int i = 0; i < ndeltas; ++i) { sp.deltas[i] = deltas[i]; sp.weights[i] = weights[i]; }
     dim3 grid((W + 63) / 64, (H + 3) / 4, NC);
-    hipLaunchKernelGGL(sig_kernel, grid, dim3(256), 0, s, out, in, H, W, sp, eps);
+    int halo = 0;
+    for (int i = 0; i < ndeltas; ++i) halo = deltas[i] < 0 ? (halo > -deltas[i] ? halo : -deltas[i]) : (halo > deltas[i] ? halo : deltas[i]);
+    hipLaunchKernelGGL(sig_kernel, grid, dim3(256), 0, s, out, in, H, W, sp, eps, halo);
 }
 
 void launch_median3x3_downsample(float *out, const float *in, int NC, int H, int W, hipStream_t s)

@@ -17,6 +17,8 @@ for k in (1, 2, 4):
     ctxs = [DemonContext(0, n) for _ in range(k)]
     for i, c in enumerate(ctxs):
         c.set_weights(w)
+        if not c.load_tuned_plan(n):
+            c.autotune(n)
         c.upload_inputs(*inputs(n, i))
     for _ in range(3):
         for c in ctxs: c.run_full(n, 3)
