@@ -19,6 +19,9 @@ namespace demon {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// n / d for the small indices of the prologue / epilogue (n < 2^20, d < 2^12) with the host-provided magic ceil(2^32 / d)
+__device__ __forceinline__ int fdiv(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }  // magic 0 <=> d == 1
+
 template <int BM, int WM, int WN, int TM, int TN, int NTAPS, int CKS, int EPT>
 __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 {
@@ -40,10 +43,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     const int zs = blockIdx.z - cls * a.ksplit;
     const int m0 = blockIdx.y * BM;
     // tile -> (image group, tile row, tile col)
-    const int tx = blockIdx.x % a.tiles_x;
-    const int tyg = blockIdx.x / a.tiles_x;
-    const int ty = tyg % a.tiles_y;
-    const int n0 = (tyg / a.tiles_y) * a.G;
+    const int tyg = fdiv(blockIdx.x, a.m_tilesx);
+    const int tx = blockIdx.x - tyg * a.tiles_x;
+    const int tgrp = fdiv(tyg, a.m_tilesy);
+    const int ty = tyg - tgrp * a.tiles_y;
+    const int n0 = tgrp * a.G;
     const int y_org = ty * a.TH * a.sh + a.oy0[cls];  // input coordinates of patch element (0,0)
     const int x_org = tx * a.TW * a.sw + a.ox0[cls];
     const float *__restrict__ wp = a.wp + (long)cls * a.cls_w_stride;
@@ -61,9 +65,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
         goff[i] = 0;
         loff[i] = 0;
         if (e < nelem) {
-            const int pl = e / plane_elems, pos = e - pl * plane_elems;
+            const int pl = fdiv(e, a.m_plane), pos = e - pl * plane_elems;
             const int g = pl / CKS, c = pl - g * CKS;
-            const int py = pos / a.PW, px = pos - py * a.PW;
+            const int py = fdiv(pos, a.m_pw), px = pos - py * a.PW;
             const int gy = y_org + py, gx = x_org + px;
             const bool ok = ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
             if (ok) goff[i] = g * (int)a.in_n_stride + c * a.H * a.W + gy * a.W + gx;
@@ -93,8 +97,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     for (int j = 0; j < TN; ++j) {
         int pj = (wn * TN + j) * 32 + l31;
         if (pj >= tile_pixels) pj = 0;  // padding lanes read a valid address; masked at the store
-        const int g = pj / (a.TH * a.TW), rem = pj - g * (a.TH * a.TW);
-        const int py = rem / a.TW, px = rem - py * a.TW;
+        const int g = fdiv(pj, a.m_thtw), rem = pj - g * (a.TH * a.TW);
+        const int py = fdiv(rem, a.m_tw), px = rem - py * a.TW;
         bbase[j] = 4 * (g * CKS * a.PS + py * a.sh * a.PW + px * a.sw + lhi * a.PS);
     }
     int so[NG];  // per k-pair: (even channel of the pair)*PS + tap offset, bytes (wave uniform)
@@ -227,8 +231,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
             const int pj = (wn * TN + j) * 32 + 4 * q;  // first of this lane's 4 pixels
             const bool pv = pj < tile_pixels;
             const int pjc = pv ? pj : 0;
-            const int g = pjc / (a.TH * a.TW), rem = pjc - g * (a.TH * a.TW);
-            const int py = rem / a.TW, px = rem - py * a.TW;
+            const int g = fdiv(pjc, a.m_thtw), rem = pjc - g * (a.TH * a.TW);
+            const int py = fdiv(rem, a.m_tw), px = rem - py * a.TW;
             const int y = ty * a.TH + py, x = tx * a.TW + px, n = n0 + g;
             const bool ok = pv && y < a.Hp && x < a.Wp && n < a.N;
             float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)y * a.Wo + x;
@@ -272,8 +276,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     for (int j = 0; j < TN; ++j) {
         const int pj = (wn * TN + j) * 32 + l31;
         if (pj >= tile_pixels) continue;
-        const int g = pj / (a.TH * a.TW), rem = pj - g * (a.TH * a.TW);
-        const int py = rem / a.TW, px = rem - py * a.TW;
+        const int g = fdiv(pj, a.m_thtw), rem = pj - g * (a.TH * a.TW);
+        const int py = fdiv(rem, a.m_tw), px = rem - py * a.TW;
         const int y = ty * a.TH + py, x = tx * a.TW + px, n = n0 + g;
         if (y >= a.Hp || x >= a.Wp || n >= a.N) continue;
         if (a.ksplit > 1) {

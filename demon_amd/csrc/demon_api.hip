@@ -346,6 +346,9 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
         while (split > 1 && (!ws || (long)L->ncls * split * L->Mpad * P > kSplitKWorkspaceFloats)) --split;
     }
     a.ksplit = split;
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };  // 0 <=> d == 1
+    a.m_plane = magic(a.PH * a.PW); a.m_pw = magic(a.PW); a.m_thtw = magic(a.TH * a.TW); a.m_tw = magic(a.TW);
+    a.m_tilesx = magic(a.tiles_x); a.m_tilesy = magic(a.tiles_y);
     return true;
 }
 

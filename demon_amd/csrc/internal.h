@@ -94,6 +94,8 @@ struct PatchArgs {
     long out_n_stride;
     int osy, osx;
     int act, ksplit, nsteps_total;
+    // magic numbers for exact unsigned division of the small prologue indices: n / d == mulhi(n, ceil(2^32 / d)) for n < 2^20, d < 2^12
+    unsigned m_plane, m_pw, m_thtw, m_tw, m_tilesx, m_tilesy;
 };
 enum PatchTileId { PTILE_128x128 = 0, PTILE_64x128, PTILE_32x128, PTILE_64x64, PTILE_128x64, PTILE_32x64, PTILE_COUNT };
 int patch_cks(int ntaps);

@@ -32,6 +32,7 @@ def get_context(batch_size=1, height=192, width=256, device=None):
         ctx = DemonContext(device, batch_size, height, width)
         if os.environ.get("DEMON_HIPGRAPH", "1") == "0":
             ctx.set_option("hipgraph", 0)
+        ctx.load_tuned_plan(batch_size)   # measured launch plan for this shape, when one is shipped (demon_amd/tuned)
         if _default_weights is not None:
             ctx.set_weights(_default_weights)
         _contexts[key] = ctx
