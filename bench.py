@@ -92,7 +92,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("DEMON_FORCE_DIST") == "1"   # the env switch exercises the RCCL path with one rank
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

@@ -26,7 +26,6 @@ template <int BM, int WM, int WN, int TM, int TN, int NTAPS, int CKS, int EPT>
 __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 {
     constexpr int NT = 64 * WM * WN;
-    constexpr int BN = WN * TN * 32;
     constexpr int KD = NTAPS * CKS;  // reduction depth of one K-step
     constexpr int NG = KD / 2;       // MFMA groups (k pairs) per step
     constexpr int A4 = KD * BM / 4;  // float4 chunks of the A tile
