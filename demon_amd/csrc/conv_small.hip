@@ -1,0 +1,176 @@
+// conv_small.hip -- the tiny contractions at the end of the heads, where a 32-row MFMA tile would be >= 87 % padding:
+//   * conv_small_kernel: 3x3 stride-1 convs with Cout <= 4 (predict_flow*/conv2, predict_depthnormal2/conv2: 24 -> 4,
+//     blocks_original.py:41-49, :263-271; predict_depth0/conv2: 16 -> 1, :511) as an LDS-tiled direct convolution on the
+//     VALU: block = 8 x 128 output pixels, each thread 4 consecutive pixels x all output channels, input staged 8 channels
+//     at a time with a 1-pixel halo, one ds_read_b128 + one ds_read_b64 per (channel, tap row).  Bandwidth bound.
+//   * motion_tail_kernel: motion_fc2 (1024 -> 128, leaky relu), motion_fc3 (128 -> 7) and the split into rotation /
+//     translation / scale (blocks_original.py:397-412) in one launch, one workgroup per sample.
+// Both read the same packed weights Wp[k][Mpad] as the MFMA kernels (k = tap*Cin + ci).
+#include "internal.h"
+
+namespace demon {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+constexpr int SM_CH = 8, SM_TH = 8, SM_TW = 128, SM_STRIDE = SM_TW + 8;  // 136 floats (cols 3..132 used): rows stay 16-byte aligned
+
+template <int CO>
+__global__ __launch_bounds__(256) void conv_small_kernel(SmallConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float tile[SM_CH][SM_TH + 2][SM_STRIDE];
+    __shared__ __attribute__((aligned(16))) float wl[64 * 9 * CO];  // weights [ci][tap][co]: uniform (broadcast) LDS reads
+    for (int e = threadIdx.x; e < a.Cin * 9 * CO; e += 256) {
+        const int co = e % CO, t = e / CO;
+        const int tap = t % 9, ci = t / 9;
+        wl[e] = co < a.Cout ? a.wp[(long)(tap * a.Cin + ci) * a.Mpad + co] : 0.0f;
+    }
+    const int n = blockIdx.z;
+    const int x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int hw = a.H * a.W;
+    const float *__restrict__ inp = a.in + (long)n * a.in_n_stride;
+    float acc[4][CO];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[p][co] = 0.0f;
+
+    for (int c0 = 0; c0 < a.Cin; c0 += SM_CH) {
+        const int nc = min(SM_CH, a.Cin - c0);
+        __syncthreads();
+        // stage [nc][10 rows][130 columns x0-1 .. x0+128], zeros outside the image; LDS column = (gx - x0) + 4 so that a
+        // thread's own four pixels start on a 16-byte boundary.  Index math is shifts only: two rows per pass for the
+        // 128 interior columns, then one pass for the two halo columns of every (channel, row).
+        {
+            const int half = threadIdx.x >> 7, col = threadIdx.x & 127;
+            const int gx = x0 + col;
+            const bool xin = gx < a.W;
+            for (int rr = 0; rr < nc * (SM_TH + 2); rr += 2) {
+                const int q = rr + half;  // (channel, row) pair index
+                if (q < nc * (SM_TH + 2)) {
+                    const int c = q / (SM_TH + 2), row = q - c * (SM_TH + 2);  // division by the constant 10
+                    const int gy = y0 - 1 + row;
+                    float v = 0.0f;
+                    if (xin && gy >= 0 && gy < a.H) v = inp[(long)(c0 + c) * hw + gy * a.W + gx];
+                    tile[c][row][col + 4] = v;
+                }
+            }
+            const int q = threadIdx.x >> 1, side = threadIdx.x & 1;
+            if (q < nc * (SM_TH + 2)) {
+                const int c = q / (SM_TH + 2), row = q - c * (SM_TH + 2);
+                const int gy = y0 - 1 + row, gxh = side ? x0 + SM_TW : x0 - 1;
+                float v = 0.0f;
+                if (gxh >= 0 && gxh < a.W && gy >= 0 && gy < a.H) v = inp[(long)(c0 + c) * hw + gy * a.W + gxh];
+                tile[c][row][side ? SM_TW + 4 : 3] = v;
+            }
+        }
+        __syncthreads();
+        for (int c = 0; c < nc; ++c) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                // values x-1 .. x+4 of row ty+dy: LDS columns 4*tx+3 .. 4*tx+8
+                const float *r = &tile[c][ty + dy][4 * tx];
+                const float vm = r[3];
+                const floatx4 v4 = *reinterpret_cast<const floatx4 *>(r + 4);
+                const float vp = r[8];
+                const float v[6] = {vm, v4[0], v4[1], v4[2], v4[3], vp};
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float *w = &wl[((c0 + c) * 9 + dy * 3 + dx) * CO];  // wave uniform address: LDS broadcast
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float wv = w[co];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[p][co] = fmaf(v[p + dx], wv, acc[p][co]);
+                    }
+                }
+            }
+        }
+    }
+    const int x = x0 + 4 * tx, y = y0 + ty;
+    if (y >= a.H || x >= a.W) return;
+    const float sc = a.scale ? a.scale[n] : 1.0f;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (co >= a.Cout) break;
+        const float b = a.bias[co];
+        float o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float v = acc[p][co] + b;
+            if (a.act) v = v >= 0.0f ? v : 0.1f * v;
+            if (co == 0) v *= sc;
+            o[p] = v;
+        }
+        float *__restrict__ dst = a.out + (long)n * a.out_n_stride + (long)co * hw + y * a.W + x;
+        if (x + 3 < a.W && (a.W & 3) == 0) {
+            *reinterpret_cast<floatx4 *>(dst) = floatx4{o[0], o[1], o[2], o[3]};
+        } else {
+            for (int p = 0; p < 4 && x + p < a.W; ++p) dst[p] = o[p];
+        }
+    }
+}
+
+bool conv_small_applies(int kh, int kw, int sh, int sw, int Cin, int Cout) { return kh == 3 && kw == 3 && sh == 1 && sw == 1 && Cout <= 4 && Cin <= 64; }
+
+void launch_conv_small(const SmallConvArgs &a, int N, hipStream_t s)
+{
+    dim3 grid((a.W + SM_TW - 1) / SM_TW, (a.H + SM_TH - 1) / SM_TH, N);
+    if (a.Cout <= 1) hipLaunchKernelGGL(conv_small_kernel<1>, grid, dim3(256), 0, s, a);
+    else if (a.Cout <= 2) hipLaunchKernelGGL(conv_small_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_small_kernel<4>, grid, dim3(256), 0, s, a);
+}
+
+// one workgroup (256 threads) per sample: h2 = lrelu(W2^T x + b2) (128), m = W3^T h2 + b3 (7) -> rotation, translation, scale.
+// fc2: thread (g = t / 32, j4 = t % 32) accumulates outputs 4*j4 .. 4*j4+3 over the K slice g (16-byte weight loads, a
+// wavefront reads two full 512-byte weight rows per step), then the 8 slices are summed through LDS.
+__global__ __launch_bounds__(256) void motion_tail_kernel(const float *__restrict__ x, const float *__restrict__ w2,
+                                                          const float *__restrict__ b2, const float *__restrict__ w3,
+                                                          const float *__restrict__ b3, float *__restrict__ motion,
+                                                          float *__restrict__ rot, float *__restrict__ trans,
+                                                          float *__restrict__ scale, int K2, int M2pad, int M3pad)
+{
+    __shared__ float xs[1024];
+    __shared__ __attribute__((aligned(16))) float part[8][128];
+    __shared__ float h2[128];
+    const int n = blockIdx.x, t = threadIdx.x;
+    for (int k = t; k < K2; k += 256) xs[k] = x[(long)n * K2 + k];
+    __syncthreads();
+    const int g = t >> 5, j4 = t & 31;
+    const int ks = K2 / 8, kb = g * ks;
+    floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+    for (int k = kb; k < kb + ks; ++k) {
+        const floatx4 w = *reinterpret_cast<const floatx4 *>(w2 + (long)k * M2pad + 4 * j4);
+        const float xv = xs[k];
+        acc[0] = fmaf(xv, w[0], acc[0]); acc[1] = fmaf(xv, w[1], acc[1]);
+        acc[2] = fmaf(xv, w[2], acc[2]); acc[3] = fmaf(xv, w[3], acc[3]);
+    }
+    *reinterpret_cast<floatx4 *>(&part[g][4 * j4]) = acc;
+    __syncthreads();
+    if (t < 128) {
+        float v = b2[t];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += part[q][t];
+        h2[t] = v >= 0.0f ? v : 0.1f * v;
+    }
+    __syncthreads();
+    if (t < 7) {
+        float v = b3[t];
+        for (int k = 0; k < 128; ++k) v = fmaf(h2[k], w3[(long)k * M3pad + t], v);
+        motion[n * 7 + t] = v;
+        if (t < 3) rot[n * 3 + t] = v;
+        else if (t < 6) trans[n * 3 + t - 3] = v;
+        else scale[n] = v;
+    }
+}
+
+void launch_motion_tail(const float *x, const float *w2, const float *b2, const float *w3, const float *b3, float *motion,
+                        float *rot, float *trans, float *scale, int N, int K2, int M2pad, int M3pad, hipStream_t s)
+{
+    hipLaunchKernelGGL(motion_tail_kernel, dim3(N), dim3(256), 0, s, x, w2, b2, w3, b3, motion, rot, trans, scale, K2, M2pad,
+                       M3pad);
+}
+
+}  // namespace demon

@@ -362,6 +362,20 @@ void launch_patch_plan(const Layer *L, PatchPlan &pp, ConvArgs &a, long P, float
     }
 }
 
+bool small_applies(const Layer *L)
+{
+    return L->kind == Layer::CONV && conv_small_applies(L->kh, L->kw, L->sh, L->sw, L->Cin, L->Cout);
+}
+
+void run_small(const Layer *L, const ConvArgs &a, hipStream_t s)
+{
+    SmallConvArgs sa;
+    sa.in = a.in; sa.out = a.out; sa.wp = a.wp; sa.bias = a.bias; sa.scale = a.scale;
+    sa.Cin = L->Cin; sa.Cout = L->Cout; sa.Mpad = L->Mpad; sa.H = a.H; sa.W = a.W; sa.act = a.act;
+    sa.in_n_stride = a.in_n_stride; sa.out_n_stride = a.out_n_stride;
+    launch_conv_small(sa, a.N, s);
+}
+
 void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
 {
     ConvArgs a;
@@ -375,7 +389,9 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
     if (const char *fp = getenv("DEMON_FORCE_PLAN")) {
         int kind = 0, tile = 0, ks = 1;
         if (sscanf(fp, "%d,%d,%d", &kind, &tile, &ks) == 3) {
-            if (kind == 1) {
+            if (kind == 3) {
+                if (small_applies(L)) { run_small(L, a, s); return; }
+            } else if (kind == 1) {
                 PatchPlan pp;
                 if (tile >= 0 && tile < PTILE_COUNT && plan_patch(L, n, ws, pp, tile)) {
                     if (ks > 0) pp.a.ksplit = ks < pp.a.nsteps_total ? ks : pp.a.nsteps_total;
@@ -392,6 +408,10 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
         auto it = L->tuned.find(n);
         if (it != L->tuned.end()) {  // measured choice (demon_autotune)
             const Layer::Tuned &t = it->second;
+            if (t.kind == 3 && small_applies(L)) {
+                run_small(L, a, s);
+                return;
+            }
             if (t.kind == 1) {
                 PatchPlan pp;
                 if (plan_patch(L, n, ws, pp, t.tile)) {
@@ -405,6 +425,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             }
         }
     }
+    if (L->force_tile < 0 && small_applies(L)) { run_small(L, a, s); return; }  // Cout <= 4 heads: VALU direct conv
     if (L->force_tile < 0 || L->force_tile >= 100) {
         PatchPlan pp;
         if (plan_patch(L, n, ws, pp, L->force_tile >= 100 ? L->force_tile - 100 : -1)) {
@@ -453,6 +474,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
             cands.push_back({1, t, ks});
         }
     }
+    if (small_applies(L)) cands.push_back({3, 0, 0});
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;
     float best = 1e30f;
@@ -486,7 +508,7 @@ struct Builder {
     bool ok = true;
 
     Layer *make(const std::string &name, Layer::Kind kind, View in, View out, int kh, int kw, int sh, int sw, int act,
-                const float *scale = nullptr)
+                const float *scale = nullptr, bool add_step = true)
     {
         auto L = std::make_unique<Layer>();
         L->name = scope + "/" + name;
@@ -512,7 +534,7 @@ struct Builder {
         st.bytes_fixed = 4.0 * ((double)p->K * p->ncls * out.C + out.C);
         float *ws = c->d_ws;
         st.fn = [p, ws](int n, hipStream_t s) { run_layer(p, n, s, ws); };
-        steps->push_back(st);
+        if (add_step) steps->push_back(st);
         return p;
     }
     // helpers.py:70-102
@@ -532,7 +554,7 @@ struct Builder {
     }
     // blocks_original.py:97-110 (lrelu) and :64-75 (linear)
     Layer *deconv(const std::string &name, View in, View out, int act) { return make(name, Layer::DECONV, in, out, 4, 4, 2, 2, act); }
-    Layer *dense(const std::string &name, View in, View out, int act) { return make(name, Layer::DENSE, in, out, 1, 1, 1, 1, act); }
+    Layer *dense(const std::string &name, View in, View out, int act, bool add_step = true) { return make(name, Layer::DENSE, in, out, 1, 1, 1, 1, act, nullptr, add_step); }
     void op(const std::string &name, const std::string &kernel, double bytes_per_sample, std::function<void(int, hipStream_t)> fn)
     {
         Step st;
@@ -659,11 +681,16 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
     View fc3;
     fc3.base = c->d_motion; fc3.Ctot = fc3.C = 7; fc3.c0 = 0; fc3.H = fc3.W = 1;
     b.dense("motion_fc1", fc_in, fc1, 1);
-    b.dense("motion_fc2", fc1, fc2, 1);
-    b.dense("motion_fc3", fc2, fc3, 0);
+    // motion_fc2 + motion_fc3 + the rotation / translation / scale split (:397-412) run as ONE small kernel; the layers are
+    // still created so that their variables exist and are packed like every other layer
+    Layer *L2 = b.dense("motion_fc2", fc1, fc2, 1, false);
+    Layer *L3 = b.dense("motion_fc3", fc2, fc3, 0, false);
     {
         float *motion = c->d_motion, *rot = c->d_rot, *trans = c->d_trans, *scale = c->d_scale;
-        b.op("split_motion", "split_motion", 56, [=](int n, hipStream_t s) { launch_split_motion(motion, rot, trans, scale, n, s); });
+        const float *x = fc1.base;
+        b.op("motion_fc2+fc3+split", "motion_tail", 4.0 * (1024 + 7), [=](int n, hipStream_t s) {
+            launch_motion_tail(x, L2->d_wp, L2->d_bias, L3->d_wp, L3->d_bias, motion, rot, trans, scale, n, 1024, L2->Mpad, L3->Mpad, s);
+        });
     }
     b.deconv("refine4/upconv", conv5_1, concat4.slice(0, 256), 1);
     b.deconv("refine3/upconv", concat4, concat3.slice(0, 128), 1);
@@ -999,11 +1026,12 @@ int demon_plan_get(const demon_ctx *c, int n, int layer_index, char *name, int n
 int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int tile, int ksplit)
 {
     if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
-    if (kind < 0 || kind > 1 || tile < 0 || tile >= (kind ? (int)PTILE_COUNT : (int)TILE_COUNT) || ksplit < 0)
+    if (kind < 0 || kind > 3 || kind == 2 || tile < 0 || tile >= (kind == 1 ? (int)PTILE_COUNT : (int)TILE_COUNT) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
             if (kind == 0 && L->Mpad % conv_tile_bm(tile)) return fail(c, DEMON_ERR_INVALID, "tile does not divide Cout");
+            if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
             c->graphs.clear();
             L->tuned[n] = Layer::Tuned{kind, tile, kind == 0 && ksplit < 1 ? 1 : ksplit};

@@ -105,6 +105,21 @@ int patch_tile_threads(int tile);
 size_t patch_lds_bytes(int tile, int ntaps, int G, int PS);
 void launch_conv_patch(const PatchArgs &a, int tile, int ntaps, int nclasses, hipStream_t stream);
 
+// ---- tiny heads (conv_small.hip): VALU direct conv for Cout <= 4, fused motion tail -------------------------------------
+struct SmallConvArgs {
+    const float *in;
+    float *out;
+    const float *wp;     // packed weights [k = tap*Cin + ci][Mpad]
+    const float *bias;
+    const float *scale;  // optional per-sample multiplier of channel 0
+    int Cin, Cout, Mpad, H, W, act;
+    long in_n_stride, out_n_stride;
+};
+bool conv_small_applies(int kh, int kw, int sh, int sw, int Cin, int Cout);
+void launch_conv_small(const SmallConvArgs &a, int N, hipStream_t s);
+void launch_motion_tail(const float *x, const float *w2, const float *b2, const float *w3, const float *b3, float *motion,
+                        float *rot, float *trans, float *scale, int N, int K2, int M2pad, int M3pad, hipStream_t s);
+
 // ---- op launchers (ops.hip) --------------------------------------------------------------------
 void launch_depth_to_flow(float *out, const float *depth, long depth_n_stride, const float *intrinsics,
                           const float *rotation, const float *translation, int N, int H, int W,
