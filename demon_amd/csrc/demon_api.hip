@@ -48,6 +48,9 @@ struct Step {
     std::string kernel;
     double flops_per_sample = 0, bytes_per_sample = 0, bytes_fixed = 0;
     std::function<void(int n, hipStream_t s)> fn;
+    // iterative nets only: 1 = conv1 / conv2 (depend on image_pair and weights only, identical in every iteration);
+    // 2 = copy of the cached conv2 output into the concat buffer (runs instead of them when the option is on)
+    int image_only = 0;
 };
 
 struct Variable {
@@ -71,7 +74,7 @@ struct demon_ctx {
     std::vector<Variable> variables;
     std::map<std::string, int> var_index;
     std::vector<Step> net_boot, net_iter, net_refine;
-    int opt_hipgraph = 1, opt_f2d_method = 0;
+    int opt_hipgraph = 1, opt_f2d_method = 0, opt_reuse_image = 0;
     std::map<std::string, hipGraphExec_t> graphs;
     // io / state
     View image_pair, image2_2, flowconf5, flowconf2, depth2, normal2, depth0;
@@ -506,6 +509,7 @@ struct Builder {
     std::vector<Step> *steps;
     std::string scope;
     bool ok = true;
+    int tag = 0;  // image_only tag given to the steps created while it is set
 
     Layer *make(const std::string &name, Layer::Kind kind, View in, View out, int kh, int kw, int sh, int sw, int act,
                 const float *scale = nullptr, bool add_step = true)
@@ -534,6 +538,7 @@ struct Builder {
         st.bytes_fixed = 4.0 * ((double)p->K * p->ncls * out.C + out.C);
         float *ws = c->d_ws;
         st.fn = [p, ws](int n, hipStream_t s) { run_layer(p, n, s, ws); };
+        st.image_only = tag;
         if (add_step) steps->push_back(st);
         return p;
     }
@@ -562,6 +567,7 @@ struct Builder {
         st.kernel = kernel;
         st.bytes_per_sample = bytes_per_sample;
         st.fn = std::move(fn);
+        st.image_only = tag;
         steps->push_back(st);
     }
 };
@@ -570,6 +576,25 @@ struct Builder {
 struct EncDec {
     View conv2cat, concat2, concat3, concat4, conv5_1;
 };
+
+// Option "reuse_image_features": conv1 / conv2 of netFlow2 and netDM2 see only image_pair and their weights, so they give the
+// same result in all iterations of one forward pass.  After them (tag 1) the result is saved to a cache buffer (tag 3, runs
+// with them in the first iteration) and a copy from the cache (tag 2) stands in for them in the later iterations.
+void add_image_cache_steps(Builder &b, const char *key, View conv2_out)
+{
+    View cache = buffer(b.c, key, conv2_out.C, conv2_out.H, conv2_out.W);
+    const long hw = (long)conv2_out.H * conv2_out.W;
+    const int C = conv2_out.C;
+    b.tag = 3;
+    b.op("save_image_features", "copy_channels", 8.0 * C * hw, [=](int n, hipStream_t s) {
+        launch_copy_channels(cache.ptr(), cache.n_stride(), conv2_out.ptr(), conv2_out.n_stride(), n, C, hw, s);
+    });
+    b.tag = 2;
+    b.op("reuse_image_features", "copy_channels", 8.0 * C * hw, [=](int n, hipStream_t s) {
+        launch_copy_channels(conv2_out.ptr(), conv2_out.n_stride(), cache.ptr(), cache.n_stride(), n, C, hw, s);
+    });
+    b.tag = 0;
+}
 
 // blocks_original.py:121-235
 void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, bool iterative)
@@ -584,11 +609,13 @@ void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope
     View concat4f = buffer(c, "concat4_flow", 514, h4, w4);
     View conv3 = buffer(c, "conv3", 128, h3, w3), conv4 = buffer(c, "conv4", 256, h4, w4);
     View conv5 = buffer(c, "conv5", 512, h5, w5), conv5_1 = buffer(c, "conv5_1", 512, h5, w5);
+    if (iterative) b.tag = 1;
     b.conv2("conv1", c->image_pair, conv1, 9, 2);
     if (!iterative) {
         b.conv2("conv2", conv1, conv2cat, 7, 2);  // 64 outputs (:144)
     } else {
         b.conv2("conv2", conv1, conv2cat.slice(0, 32), 7, 2);
+        add_image_cache_steps(b, "flow2_conv2_cache", conv2cat.slice(0, 32));
         View extra = buffer(c, "extra_flow", 9, h2, w2);  // [warped 3, flow 2, depth 1, normal 3] (:180)
         View img2 = c->image2_2, depth2 = c->depth2, normal2 = c->normal2;
         float *rot = c->d_rot, *trans = c->d_trans, *intr = c->d_intrinsics;
@@ -642,8 +669,10 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
     View concat4 = buffer(c, "concat4_dm", 512, h4, w4);
     View conv3 = buffer(c, "conv3", 128, h3, w3), conv4 = buffer(c, "conv4", 256, h4, w4);
     View conv5 = buffer(c, "conv5", 512, h5, w5), conv5_1 = buffer(c, "conv5_1", 512, h5, w5);
+    if (iterative) b.tag = 1;
     b.conv2("conv1", c->image_pair, conv1, 9, 2);
     b.conv2("conv2", conv1, conv2cat.slice(0, 32), 7, 2);
+    if (iterative) add_image_cache_steps(b, "dm2_conv2_cache", conv2cat.slice(0, 32));
     const int nextra = iterative ? 8 : 7;  // [warped 3, flowconf 4, depth_from_flow 1] (:341, :362)
     View extra = buffer(c, iterative ? "extra_dm8" : "extra_dm7", nextra, h2, w2);
     View img2 = c->image2_2, flowconf2 = c->flowconf2;
@@ -740,9 +769,16 @@ bool weights_ready(demon_ctx *c, std::string *missing)
     return true;
 }
 
-void run_steps(const std::vector<Step> &steps, int n, hipStream_t s)
+// mode 0: plain (every layer, no cache traffic); 1: first iteration with the option on (layers + save); 2: later iterations
+// (cached conv2 output instead of the image-only layers)
+void run_steps(const std::vector<Step> &steps, int n, hipStream_t s, int mode = 0)
 {
-    for (const Step &st : steps) st.fn(n, s);
+    for (const Step &st : steps) {
+        if (st.image_only == 1 && mode == 2) continue;
+        if (st.image_only == 2 && mode != 2) continue;
+        if (st.image_only == 3 && mode != 1) continue;
+        st.fn(n, s);
+    }
 }
 
 enum SeqKind { SEQ_BOOT = 0, SEQ_ITER, SEQ_REFINE, SEQ_FULL };
@@ -752,7 +788,7 @@ void enqueue_sequence(demon_ctx *c, int kind, int n, int iterations, hipStream_t
     if (kind == SEQ_BOOT || kind == SEQ_FULL) run_steps(c->net_boot, n, s);
     if (kind == SEQ_ITER) run_steps(c->net_iter, n, s);
     if (kind == SEQ_FULL)
-        for (int i = 0; i < iterations; ++i) run_steps(c->net_iter, n, s);
+        for (int i = 0; i < iterations; ++i) run_steps(c->net_iter, n, s, c->opt_reuse_image ? (i == 0 ? 1 : 2) : 0);
     if (kind == SEQ_REFINE || kind == SEQ_FULL) run_steps(c->net_refine, n, s);
 }
 
@@ -765,7 +801,7 @@ int run_sequence(demon_ctx *c, int kind, int n, int iterations)
         return DEMON_OK;
     }
     char key[64];
-    snprintf(key, sizeof key, "%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method);
+    snprintf(key, sizeof key, "%d:%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method, c->opt_reuse_image);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -992,6 +1028,7 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
         c->opt_f2d_method = value;
         return DEMON_OK;
     }
+    if (!strcmp(key, "reuse_image_features")) { c->opt_reuse_image = value ? 1 : 0; return DEMON_OK; }
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }
 
@@ -1161,7 +1198,8 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
     std::vector<const Step *> seq;
     for (auto &s : c->net_boot) seq.push_back(&s);
     for (int i = 0; i < iterations; ++i)
-        for (auto &s : c->net_iter) seq.push_back(&s);
+        for (auto &s : c->net_iter)
+            if (s.image_only < 2) seq.push_back(&s);
     for (auto &s : c->net_refine) seq.push_back(&s);
     std::vector<hipEvent_t> ev(2 * seq.size());
     for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));

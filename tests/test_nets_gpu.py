@@ -202,3 +202,18 @@ def test_example_script_runs_on_an_image_pair(tmp_path, synth_weights):
     res = np.load(out)
     assert res["predict_depth0"].shape == (1, 1, 192, 256) and np.isfinite(res["predict_depth0"]).all()
     assert res["rotation"].shape == (1, 3) and res["translation"].shape == (1, 3)
+
+
+def test_reuse_image_features_option_is_exact(gpu_ctx):
+    """opt-in loop-invariant reuse (conv1 / conv2 of the iterative nets computed once per forward): bit-identical outputs"""
+    pair, img2_2 = make_inputs(2, seed=14)
+    base = gpu_ctx.full(pair, img2_2, iterations=3)
+    gpu_ctx.set_option("reuse_image_features", 1)
+    try:
+        fast = gpu_ctx.full(pair, img2_2, iterations=3)
+        one = gpu_ctx.full(pair, img2_2, iterations=1)
+    finally:
+        gpu_ctx.set_option("reuse_image_features", 0)
+    for k in KEYS + ("predict_depth0",):
+        np.testing.assert_array_equal(fast[k], base[k])
+    assert np.isfinite(one["predict_depth0"]).all()
