@@ -29,6 +29,7 @@ GFLOP_PER_PAIR = 30.353      # 2*MAC of conv/deconv/dense
 WORKLOADS = {
     "full": (192, 256, 32, 30.353, "configs[2]: batch %d/GPU synthetic 256x192 pairs, bootstrap + %d x iterative + refine, device-resident, hipGraph on"),
     "bootstrap": (192, 256, 8, 6.193, "configs[1]: batch %d/GPU synthetic 256x192 pairs, bootstrap net only (netFlow1 + netDM1), device-resident, hipGraph on"),
+    "v2": (192, 256, 32, None, "v2 model (python/depthmotionnet/v2, SURVEY 8f row 3): batch %d/GPU synthetic 256x192 pairs, bootstrap + %d x iterative + refine, device-resident, hipGraph on"),
     "hires": (480, 640, 64, 189.70, "configs[4]: batch %d/GPU synthetic 640x480 pairs, bootstrap + %d x iterative + refine, synthetic motion_fc1 38400x1024, hipGraph on"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
@@ -71,7 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (default: the workload's batch)")
     ap.add_argument("--iterations", type=int, default=3)
-    ap.add_argument("--workload", choices=["full", "bootstrap", "hires"], default="full",
+    ap.add_argument("--workload", choices=["full", "bootstrap", "hires", "v2"], default="full",
                     help="full = BASELINE configs[2] (default, the metric's configuration); bootstrap = configs[1] "
                          "(batch 8, bootstrap net only); hires = configs[4] (batch 64, 640x480, full pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,14 +105,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback for the product path")
     torch.cuda.set_device(local_rank)
 
-    ctx = DemonContext(device=local_rank, max_batch=args.batch, height=height, width=width)
+    version = 2 if args.workload == "v2" else 1
+    ctx = DemonContext(device=local_rank, max_batch=args.batch, height=height, width=width, version=version)
     order = ctx.variables()
     nblob = ctx.blob_size()
     # weights: rank 0 creates the blob, one RCCL broadcast over xGMI puts it on every GPU
     host_weights = None
     t_bcast = 0.0
     if rank == 0:
-        host_weights = W.synthetic_weights(seed=1, height=height, width=width)
+        host_weights = W.synthetic_weights(seed=1, height=height, width=width, version=version)
         blob = torch.from_numpy(W.weights_to_blob(host_weights, order)).cuda()
     else:
         blob = torch.empty(nblob, dtype=torch.float32, device="cuda")
@@ -173,7 +175,8 @@ def main():
         value = pairs / elapsed
         result = {
             "metric": ("image-pairs/s full 3-iter DeMoN forward @256x192" + (" (image features hoisted out of the iteration loop)" if args.reuse_image_features else "")) if args.workload == "full" else
-                      ("image-pairs/s bootstrap net @256x192" if boot_only else "image-pairs/s full 3-iter DeMoN forward @640x480"),
+                      ("image-pairs/s bootstrap net @256x192" if boot_only else
+                       ("image-pairs/s full 3-iter DeMoN v2 forward @256x192" if version == 2 else "image-pairs/s full 3-iter DeMoN forward @640x480")),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -182,15 +185,19 @@ def main():
                        "sharding": "independent pairs per rank, no data-path collective",
                        "weights": "synthetic He-normal seed 1, RCCL broadcast %.1f ms (untimed)" % (1e3 * t_bcast),
                        "launch_plan": plan_src, "plan_setup_s": round(t_tune, 2)},
-            "pipeline_mfma_frac": value / world * gflop_pair * 1e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "outputs_finite": bool(finite),
         }
+        if gflop_pair:
+            result["pipeline_mfma_frac"] = value / world * gflop_pair * 1e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12)
         if not args.no_roofline and not boot_only:
             recs = ctx.profile_full(n, args.iterations, repeats=3)
             conv = [r for r in recs if r["kernel"] == "conv_mfma"]
             ms = sum(r["ms"] for r in conv)
             flops = sum(r["flops"] for r in conv)
             achieved = flops / (ms * 1e-3) / 1e12
+            if not gflop_pair:   # no published per-pair figure for this workload: 2*MAC of the launched conv / deconv / dense layers
+                result["gflop_per_pair"] = flops / n / 1e9
+                result["pipeline_mfma_frac"] = value / world * flops / n / (PEAK_FP32_MFMA_TFLOPS * 1e12)
             result["roofline"] = {
                 "kernel": "conv_mfma_kernel (fp32 MFMA implicit GEMM; all conv / deconv / dense launches)",
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -31,6 +31,8 @@ _I = ctypes.c_int
 _F = ctypes.c_float
 SIGNATURES = {
     "demon_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
+    "demon_create_v2": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
+    "demon_variant": (_I, [_P]),
     "demon_destroy": (_I, [_P]),
     "demon_last_error": (ctypes.c_char_p, [_P]),
     "demon_device": (_I, [_P]),
@@ -55,6 +57,7 @@ SIGNATURES = {
     "demon_run_bootstrap": (_I, [_P, _I]),
     "demon_synchronize": (_I, [_P]),
     "demon_download_outputs": (_I, [_P, _I, ctypes.POINTER(DemonOutputs), c_float_p]),
+    "demon_download_normal0": (_I, [_P, _I, c_float_p]),
     "demon_time_full": (_I, [_P, _I, _I, _I, c_float_p]),
     "demon_profile_full": (_I, [_P, _I, _I, _I, ctypes.POINTER(LaunchRecord), _I, c_int_p]),
     "demon_op_depth_to_flow": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, _I, _I, _I, _I, _I, _I]),

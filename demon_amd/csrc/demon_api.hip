@@ -66,6 +66,7 @@ struct Variable {
 
 struct demon_ctx {
     int device = 0, max_batch = 0, H = 0, W = 0;
+    int variant = 1;  // 1 = networks_original.py / blocks_original.py, 2 = v2/networks.py / v2/blocks.py
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void *> allocations;
@@ -77,7 +78,7 @@ struct demon_ctx {
     int opt_hipgraph = 1, opt_f2d_method = 0, opt_reuse_image = 0;
     std::map<std::string, hipGraphExec_t> graphs;
     // io / state
-    View image_pair, image2_2, flowconf5, flowconf2, depth2, normal2, depth0;
+    View image_pair, image2_2, flowconf5, flowconf2, depth2, normal2, depth0, normal0;
     float *d_rot = nullptr, *d_trans = nullptr, *d_scale = nullptr, *d_motion = nullptr, *d_intrinsics = nullptr;
     float *d_ws = nullptr;  // split-K workspace
 };
@@ -510,6 +511,9 @@ struct Builder {
     std::string scope;
     bool ok = true;
     int tag = 0;  // image_only tag given to the steps created while it is set
+    // false: helpers.py:70-153 zero-pad k//2 on both sides then VALID; true: v2/helpers.py:24-91 padding='same', which for the
+    // even input sizes of this net puts (k - stride) // 2 zeros in front and the rest behind
+    bool same = false;
 
     Layer *make(const std::string &name, Layer::Kind kind, View in, View out, int kh, int kw, int sh, int sw, int act,
                 const float *scale = nullptr, bool add_step = true)
@@ -519,6 +523,7 @@ struct Builder {
         L->kind = kind;
         L->Cin = in.C; L->Cout = out.C;
         L->kh = kh; L->kw = kw; L->sh = sh; L->sw = sw; L->ph = kh / 2; L->pw = kw / 2; L->act = act;
+        if (same) { L->ph = kh > sh ? (kh - sh) / 2 : 0; L->pw = kw > sw ? (kw - sw) / 2 : 0; }
         L->in = in; L->out = out; L->scale = scale;
         if (kind == Layer::CONV) L->kernel_dims = {kh, kw, in.C, out.C};
         else if (kind == Layer::DECONV) L->kernel_dims = {4, 4, out.C, in.C};
@@ -547,13 +552,15 @@ struct Builder {
     {
         return make(name, Layer::CONV, in, out, k, k, stride, stride, act, scale);
     }
-    // helpers.py:105-153: <name>y = k x 1 stride (s,1), <name>x = 1 x k stride (1,s), both leaky relu
-    void conv2(const std::string &name, View in, View out, int k, int s)
+    // helpers.py:105-153: <name>y = k x 1 stride (s,1), <name>x = 1 x k stride (1,s), both leaky relu;
+    // v2/helpers.py:44-91: the same pair with `cy` outputs of the first filter ((24,32), (48,64), ...)
+    void conv2(const std::string &name, View in, View out, int k, int s, int cy = 0)
     {
-        const int Hmid = (in.H + 2 * (k / 2) - k) / s + 1;
+        const int Hmid = (in.H + 2 * (k / 2) - k) / s + 1;  // == ceil(H / s), the 'same' size, for the even H of this net
+        if (!cy) cy = out.C;
         char key[64];
-        snprintf(key, sizeof key, "tmp_y_%dx%dx%d", out.C, Hmid, in.W);
-        View mid = buffer(c, key, out.C, Hmid, in.W);
+        snprintf(key, sizeof key, "tmp_y_%dx%dx%d", cy, Hmid, in.W);
+        View mid = buffer(c, key, cy, Hmid, in.W);
         make(name + "y", Layer::CONV, in, mid, k, 1, s, 1, 1);
         make(name + "x", Layer::CONV, mid, out, 1, k, 1, s, 1);
     }
@@ -596,10 +603,36 @@ void add_image_cache_steps(Builder &b, const char *key, View conv2_out)
     b.tag = 0;
 }
 
-// blocks_original.py:121-235
+// Channel plan of the shared encoder: blocks_original.py:141-153 / v2/blocks.py:141-195 (v2: asymmetric 1-D pairs, 384 at level 5)
+struct EncPlan {
+    int c1y, c2y_boot, c3y, c4y, c5;
+};
+EncPlan enc_plan(const demon_ctx *c)
+{
+    return c->variant == 2 ? EncPlan{24, 48, 96, 192, 384} : EncPlan{32, 64, 128, 256, 512};
+}
+
+// v2/blocks.py:197-213 (flow block), :395-411 (depth+motion block): the first 96 channels of conv5_1, flattened in C,H,W order
+// (= the first 96*h5*w5 floats of each sample of the NCHW buffer), go through a square dense layer and come back as 96 more
+// channels behind conv5_1.  `feat` is the [384 + 96, h5, w5] buffer whose first 384 channels conv5_1 has just written.
+void add_dense5(Builder &b, View feat)
+{
+    const int hw = feat.H * feat.W, units = 96 * hw;
+    View in = feat, out = feat;
+    in.Ctot = out.Ctot = feat.Ctot * hw;
+    in.H = in.W = out.H = out.W = 1;
+    in.c0 = 0; in.C = units;
+    out.c0 = (feat.Ctot - 96) * hw; out.C = units;
+    b.dense("dense5", in, out, 1);
+}
+
+// blocks_original.py:121-235; v2/blocks.py:120-253
 void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, bool iterative)
 {
     Builder b{c, steps, scope};
+    const bool v2 = c->variant == 2;
+    const EncPlan ep = enc_plan(c);
+    b.same = v2;
     const int H = c->H, W = c->W, h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8, h4 = H / 16,
               w4 = W / 16, h5 = H / 32, w5 = W / 32;
     View conv1 = buffer(c, "conv1", 32, h1, w1);
@@ -608,15 +641,17 @@ void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope
     View concat3 = buffer(c, "concat3", 256, h3, w3);
     View concat4f = buffer(c, "concat4_flow", 514, h4, w4);
     View conv3 = buffer(c, "conv3", 128, h3, w3), conv4 = buffer(c, "conv4", 256, h4, w4);
-    View conv5 = buffer(c, "conv5", 512, h5, w5), conv5_1 = buffer(c, "conv5_1", 512, h5, w5);
+    View conv5 = buffer(c, "conv5", ep.c5, h5, w5);
+    View feat5 = buffer(c, "conv5_1", v2 ? ep.c5 + 96 : ep.c5, h5, w5);  // v2: [conv5_1 384, dense5 96] (v2/blocks.py:213)
+    View conv5_1 = feat5.slice(0, ep.c5);
     if (iterative) b.tag = 1;
-    b.conv2("conv1", c->image_pair, conv1, 9, 2);
+    b.conv2("conv1", c->image_pair, conv1, 9, 2, ep.c1y);
     if (!iterative) {
-        b.conv2("conv2", conv1, conv2cat, 7, 2);  // 64 outputs (:144)
+        b.conv2("conv2", conv1, conv2cat, 7, 2, ep.c2y_boot);  // 64 outputs (:144; v2 :144 (48,64))
     } else {
         b.conv2("conv2", conv1, conv2cat.slice(0, 32), 7, 2);
         add_image_cache_steps(b, "flow2_conv2_cache", conv2cat.slice(0, 32));
-        View extra = buffer(c, "extra_flow", 9, h2, w2);  // [warped 3, flow 2, depth 1, normal 3] (:180)
+        View extra = buffer(c, "extra_flow", 9, h2, w2);  // [warped 3, flow 2, depth 1, normal 3] (:180; v2 :180)
         View img2 = c->image2_2, depth2 = c->depth2, normal2 = c->normal2;
         float *rot = c->d_rot, *trans = c->d_trans, *intr = c->d_intrinsics;
         const double px = (double)h2 * w2 * 4;
@@ -637,17 +672,18 @@ void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope
         b.conv2("conv2_extra_inputs", extra, conv2cat.slice(32, 32), 3, 1);
     }
     b.conv2("conv2_1", conv2cat, concat2.slice(64, 64), 3, 1);
-    b.conv2("conv3", concat2.slice(64, 64), conv3, 5, 2);
+    b.conv2("conv3", concat2.slice(64, 64), conv3, 5, 2, ep.c3y);
     b.conv2("conv3_1", conv3, concat3.slice(128, 128), 3, 1);
-    b.conv2("conv4", concat3.slice(128, 128), conv4, 5, 2);
+    b.conv2("conv4", concat3.slice(128, 128), conv4, 5, 2, ep.c4y);
     b.conv2("conv4_1", conv4, concat4f.slice(256, 256), 3, 1);
     b.conv2("conv5", concat4f.slice(256, 256), conv5, 5, 2);
     b.conv2("conv5_1", conv5, conv5_1, 3, 1);
+    if (v2) add_dense5(b, feat5);
     View pf5 = buffer(c, "predict5_tmp", 24, h5, w5);
-    b.conv("predict_flow5/conv1", conv5_1, pf5, 3, 1, 1);
+    b.conv("predict_flow5/conv1", feat5, pf5, 3, 1, 1);
     b.conv("predict_flow5/conv2", pf5, c->flowconf5, 3, 1, 0);
     b.deconv("upsample_flow5to4/upconv", c->flowconf5, concat4f.slice(512, 2), 0);
-    b.deconv("refine4/upconv", conv5_1, concat4f.slice(0, 256), 1);
+    b.deconv("refine4/upconv", feat5, concat4f.slice(0, 256), 1);
     b.deconv("refine3/upconv", concat4f, concat3.slice(0, 128), 1);
     b.deconv("refine2/upconv", concat3, concat2.slice(0, 64), 1);
     View pf2 = buffer(c, "predict2_tmp", 24, h2, w2);
@@ -656,10 +692,13 @@ void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope
     if (!b.ok) c->err = "device allocation failed while building " + scope;
 }
 
-// blocks_original.py:299-448
+// blocks_original.py:299-448; v2/blocks.py:317-494
 void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, bool iterative)
 {
     Builder b{c, steps, scope};
+    const bool v2 = c->variant == 2;
+    const EncPlan ep = enc_plan(c);
+    b.same = v2;
     const int H = c->H, W = c->W, h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4, h3 = H / 8, w3 = W / 8, h4 = H / 16,
               w4 = W / 16, h5 = H / 32, w5 = W / 32;
     View conv1 = buffer(c, "conv1", 32, h1, w1);
@@ -668,12 +707,14 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
     View concat3 = buffer(c, "concat3", 256, h3, w3);
     View concat4 = buffer(c, "concat4_dm", 512, h4, w4);
     View conv3 = buffer(c, "conv3", 128, h3, w3), conv4 = buffer(c, "conv4", 256, h4, w4);
-    View conv5 = buffer(c, "conv5", 512, h5, w5), conv5_1 = buffer(c, "conv5_1", 512, h5, w5);
+    View conv5 = buffer(c, "conv5", ep.c5, h5, w5);
+    View feat5 = buffer(c, "conv5_1", v2 ? ep.c5 + 96 : ep.c5, h5, w5);
+    View conv5_1 = feat5.slice(0, ep.c5);
     if (iterative) b.tag = 1;
-    b.conv2("conv1", c->image_pair, conv1, 9, 2);
+    b.conv2("conv1", c->image_pair, conv1, 9, 2, ep.c1y);
     b.conv2("conv2", conv1, conv2cat.slice(0, 32), 7, 2);
     if (iterative) add_image_cache_steps(b, "dm2_conv2_cache", conv2cat.slice(0, 32));
-    const int nextra = iterative ? 8 : 7;  // [warped 3, flowconf 4, depth_from_flow 1] (:341, :362)
+    const int nextra = iterative ? 8 : 7;  // [warped 3, flowconf 4, depth_from_flow 1] (:341, :362; v2 :359, :381)
     View extra = buffer(c, iterative ? "extra_dm8" : "extra_dm7", nextra, h2, w2);
     View img2 = c->image2_2, flowconf2 = c->flowconf2;
     const double px = (double)h2 * w2 * 4;
@@ -688,22 +729,32 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
     if (iterative) {
         float *rot = c->d_rot, *trans = c->d_trans, *intr = c->d_intrinsics;
         demon_ctx *cc = c;
+        // v2: flow_to_depth2 followed by clip_by_value(0, 50) (v2/blocks.py:362-379), regardless of the option
         b.op("flow_to_depth", "flow_to_depth", px * 3, [=](int n, hipStream_t s) {
             launch_flow_to_depth(extra.slice(7, 1).ptr(), extra.n_stride(), flowconf2.ptr(), flowconf2.n_stride(), intr,
-                                 rot, trans, n, h2, w2, 1, 1, cc->opt_f2d_method, s);
+                                 rot, trans, n, h2, w2, 1, 1, v2 ? 1 : cc->opt_f2d_method, v2 ? 50.0f : 0.0f, s);
         });
     }
     b.conv2("conv2_extra_inputs", extra, conv2cat.slice(32, 32), 3, 1);
     b.conv2("conv2_1", conv2cat, concat2.slice(64, 64), 3, 1);
-    b.conv2("conv3", concat2.slice(64, 64), conv3, 5, 2);
+    b.conv2("conv3", concat2.slice(64, 64), conv3, 5, 2, ep.c3y);
     b.conv2("conv3_1", conv3, concat3.slice(128, 128), 3, 1);
-    b.conv2("conv4", concat3.slice(128, 128), conv4, 5, 2);
+    b.conv2("conv4", concat3.slice(128, 128), conv4, 5, 2, ep.c4y);
     b.conv2("conv4_1", conv4, concat4.slice(256, 256), 3, 1);
-    b.conv2("conv5", concat4.slice(256, 256), conv5, 3, 2);  // k = 3 (:375)
+    b.conv2("conv5", concat4.slice(256, 256), conv5, 3, 2);  // k = 3 (:375; v2 :392)
     b.conv2("conv5_1", conv5, conv5_1, 3, 1);
-    // motion head (:380-412); flatten is C,H,W order = NCHW memory order
+    // motion head (:380-412; v2 :413-457); flatten is C,H,W order = NCHW memory order
     View mconv = buffer(c, "motion_conv1", 128, h5, w5);
-    b.conv("motion_conv1", conv5_1, mconv, 3, 1, 1);
+    if (!v2) {
+        b.conv("motion_conv1", conv5_1, mconv, 3, 1, 1);
+    } else {
+        add_dense5(b, feat5);
+        View m3 = buffer(c, "motion_conv3", 64, h3, w3), m4 = buffer(c, "motion_conv4", 64, h4, w4);
+        b.conv2("motion_conv3", concat2.slice(64, 64), m3, 5, 2);
+        b.conv2("motion_conv4", m3, m4, 5, 2);
+        b.conv2("motion_conv5a", m4, mconv.slice(0, 64), 3, 2);
+        b.conv("motion_conv5b", feat5, mconv.slice(64, 64), 3, 1, 1);
+    }
     View fc_in = mconv;
     fc_in.C = fc_in.Ctot = 128 * h5 * w5; fc_in.H = fc_in.W = 1;
     View fc1 = buffer(c, "motion_fc1", 1024, 1, 1), fc2 = buffer(c, "motion_fc2", 128, 1, 1);
@@ -721,22 +772,23 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
             launch_motion_tail(x, L2->d_wp, L2->d_bias, L3->d_wp, L3->d_bias, motion, rot, trans, scale, n, 1024, L2->Mpad, L3->Mpad, s);
         });
     }
-    b.deconv("refine4/upconv", conv5_1, concat4.slice(0, 256), 1);
+    b.deconv("refine4/upconv", conv5_1, concat4.slice(0, 256), 1);  // v2 too: conv5_1 without dense5 (v2/blocks.py:462)
     b.deconv("refine3/upconv", concat4, concat3.slice(0, 128), 1);
     b.deconv("refine2/upconv", concat3, concat2.slice(0, 64), 1);
     View pd = buffer(c, "predict2_tmp", 24, h2, w2);
-    View dn = buffer(c, "depthnormal2", 4, h2, w2);  // ch 0 = scale*depth, ch 1:4 = normal (:278-287)
+    View dn = buffer(c, "depthnormal2", 4, h2, w2);  // ch 0 = scale*depth, ch 1:4 = normal (:278-287; v2 :294-305)
     b.conv("predict_depthnormal2/conv1", concat2, pd, 3, 1, 1);
     b.conv("predict_depthnormal2/conv2", pd, dn, 3, 1, 0, c->d_scale);
     if (!b.ok) c->err = "device allocation failed while building " + scope;
 }
 
-// blocks_original.py:452-513
+// blocks_original.py:452-513; v2/blocks.py:499-562 (4 output channels: depth + normal)
 void build_refine(demon_ctx *c, std::vector<Step> *steps)
 {
     Builder b{c, steps, "netRefine"};
+    b.same = c->variant == 2;
     const int H = c->H, W = c->W, h1 = H / 2, w1 = W / 2, h2 = H / 4, w2 = W / 4;
-    View inp = buffer(c, "refine_in", 4, H, W);  // [image1 3, depth2 upsampled 1] (:482)
+    View inp = buffer(c, "refine_in", 4, H, W);  // [image1 3, depth2 upsampled 1] (:482; v2 :527)
     View concat0 = buffer(c, "refine_concat0", 64, H, W);
     View concat1 = buffer(c, "refine_concat1", 128, h1, w1);
     View r1 = buffer(c, "refine_conv1", 64, h1, w1), r2 = buffer(c, "refine_conv2", 128, h2, w2),
@@ -755,7 +807,10 @@ void build_refine(demon_ctx *c, std::vector<Step> *steps)
     b.deconv("refine0/upconv", concat1, concat0.slice(0, 32), 1);
     View p0 = buffer(c, "predict0_tmp", 16, H, W);
     b.conv("predict_depth0/conv1", concat0, p0, 3, 1, 1);
-    b.conv("predict_depth0/conv2", p0, c->depth0, 3, 1, 0);
+    // v1: c->depth0 is a 1-channel buffer; v2: [depth0, normal0 xyz] in one 4-channel buffer (v2/blocks.py:560)
+    View head = c->depth0;
+    if (c->variant == 2) head.C = 4;
+    b.conv("predict_depth0/conv2", p0, head, 3, 1, 0);
     if (!b.ok) c->err = "device allocation failed while building netRefine";
 }
 
@@ -881,7 +936,7 @@ struct TmpDev {
 // =====================================================================================================
 extern "C" {
 
-int demon_create(demon_ctx **out, int device, int max_batch, int height, int width)
+static int create_impl(demon_ctx **out, int device, int max_batch, int height, int width, int variant)
 {
     if (!out) return fail(nullptr, DEMON_ERR_INVALID, "null ctx pointer");
     *out = nullptr;
@@ -893,7 +948,7 @@ int demon_create(demon_ctx **out, int device, int max_batch, int height, int wid
     if (device < 0 || device >= ndev) return fail(nullptr, DEMON_ERR_INVALID, "device index out of range");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, DEMON_ERR_HIP, "hipSetDevice failed");
     std::unique_ptr<demon_ctx> c(new demon_ctx);
-    c->device = device; c->max_batch = max_batch; c->H = height; c->W = width;
+    c->device = device; c->max_batch = max_batch; c->H = height; c->W = width; c->variant = variant;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
         return fail(nullptr, DEMON_ERR_HIP, "hipStreamCreate failed");
     demon_ctx *p = c.get();
@@ -906,7 +961,8 @@ int demon_create(demon_ctx **out, int device, int max_batch, int height, int wid
     // stage reads (prev depth2 / normal2, blocks_original.py:180) are slices of it, so nothing is copied
     p->depth2 = buffer(p, "depthnormal2", 4, h2, w2).slice(0, 1);
     p->normal2 = buffer(p, "depthnormal2", 4, h2, w2).slice(1, 3);
-    p->depth0 = buffer(p, "depth0", 1, height, width);
+    p->depth0 = buffer(p, "depth0", variant == 2 ? 4 : 1, height, width).slice(0, 1);
+    p->normal0 = buffer(p, "depth0", variant == 2 ? 4 : 1, height, width).slice(1, 3);  // v2 only
     p->d_rot = dev_alloc(p, sizeof(float) * 3 * max_batch);
     p->d_trans = dev_alloc(p, sizeof(float) * 3 * max_batch);
     p->d_scale = dev_alloc(p, sizeof(float) * max_batch);
@@ -938,6 +994,18 @@ int demon_create(demon_ctx **out, int device, int max_batch, int height, int wid
     *out = c.release();
     return DEMON_OK;
 }
+
+int demon_create(demon_ctx **out, int device, int max_batch, int height, int width)
+{
+    return create_impl(out, device, max_batch, height, width, 1);
+}
+
+int demon_create_v2(demon_ctx **out, int device, int max_batch, int height, int width)
+{
+    return create_impl(out, device, max_batch, height, width, 2);
+}
+
+int demon_variant(const demon_ctx *c) { return c ? c->variant : 0; }
 
 int demon_destroy(demon_ctx *c)
 {
@@ -1124,6 +1192,17 @@ int demon_download_outputs(demon_ctx *c, int n, const demon_outputs *o, float *d
     return DEMON_OK;
 }
 
+int demon_download_normal0(demon_ctx *c, int n, float *normal0)
+{
+    if (!c || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad batch");
+    if (c->variant != 2) return fail(c, DEMON_ERR_INVALID, "predict_normal0 exists only in v2 contexts (demon_create_v2)");
+    hipSetDevice(c->device);
+    int r = d2h(c, normal0, c->normal0, n);
+    if (r) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DEMON_OK;
+}
+
 int demon_bootstrap(demon_ctx *c, int n, const float *image_pair, const float *image2_2, const demon_outputs *o)
 {
     int r = demon_upload_inputs(c, n, image_pair, image2_2);
@@ -1267,7 +1346,7 @@ int demon_op_flow_to_depth(demon_ctx *c, float *out, const float *flow, const fl
     float *d_flow = tmp.upload(flow, 2 * n * hw), *d_k = tmp.upload(intrinsics, 4 * n), *d_r = tmp.upload(rotation, 3 * n),
           *d_t = tmp.upload(translation, 3 * n), *d_out = tmp.alloc(n * hw);
     if (!d_flow || !d_k || !d_r || !d_t || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
-    launch_flow_to_depth(d_out, hw, d_flow, 2 * hw, d_k, d_r, d_t, n, h, w, inverse_depth, normalized_flow, method, c->stream);
+    launch_flow_to_depth(d_out, hw, d_flow, 2 * hw, d_k, d_r, d_t, n, h, w, inverse_depth, normalized_flow, method, 0.0f, c->stream);
     OP_FINISH(c, d_out, out, n * hw);
 }
 
@@ -1331,7 +1410,7 @@ int demon_op_median3x3_downsample(demon_ctx *c, float *out, const float *in, int
 
 // one stand-alone contraction layer through the same packing + kernel path the networks use
 static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const float *in, const float *w, const float *bias,
-                            int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw, int lrelu)
+                            int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw, int lrelu, bool same = false)
 {
     if (!c) return DEMON_ERR_INVALID;
     hipSetDevice(c->device);
@@ -1346,7 +1425,12 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
     int ho, wo;
     if (kind == Layer::DECONV) { ho = 2 * h; wo = 2 * wd; }
     else if (kind == Layer::DENSE) { ho = 1; wo = 1; }
-    else { ho = (h + 2 * L.ph - kh) / sh + 1; wo = (wd + 2 * L.pw - kw) / sw + 1; }
+    else if (same) {
+        // tf.layers.conv2d(padding='same') (v2/helpers.py:24-35): out = ceil(n / s), zeros in front = pad_total // 2
+        ho = (h + sh - 1) / sh; wo = (wd + sw - 1) / sw;
+        const int th = (ho - 1) * sh + kh - h, tw = (wo - 1) * sw + kw - wd;
+        L.ph = th > 0 ? th / 2 : 0; L.pw = tw > 0 ? tw / 2 : 0;
+    } else { ho = (h + 2 * L.ph - kh) / sh + 1; wo = (wd + 2 * L.pw - kw) / sw + 1; }
     L.in = buffer(&scratch, "in", cin, h, wd);
     L.out = buffer(&scratch, "out", cout, ho, wo);
     int rc = DEMON_OK;
@@ -1427,8 +1511,10 @@ int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int
 int demon_op_conv2d(demon_ctx *c, float *out, const float *in, const float *w_hwio, const float *bias, int n, int cin, int h,
                     int w, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int lrelu)
 {
-    if (c && (ph != kh / 2 || pw != kw / 2)) return fail(c, DEMON_ERR_INVALID, "only caffe-style padding k/2 is supported (helpers.py:78-79)");
-    return run_single_layer(c, Layer::CONV, out, in, w_hwio, bias, n, cin, h, w, cout, kh, kw, sh, sw, lrelu);
+    const bool same = ph == -1 && pw == -1;
+    if (c && !same && (ph != kh / 2 || pw != kw / 2))
+        return fail(c, DEMON_ERR_INVALID, "padding must be k/2 (helpers.py:78-79) or -1,-1 for TF 'same' (v2/helpers.py:24-35)");
+    return run_single_layer(c, Layer::CONV, out, in, w_hwio, bias, n, cin, h, w, cout, kh, kw, sh, sw, lrelu, same);
 }
 
 int demon_op_deconv4x4s2(demon_ctx *c, float *out, const float *in, const float *w_hwoi, const float *bias, int n, int cin,

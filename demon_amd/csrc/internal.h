@@ -126,7 +126,7 @@ void launch_depth_to_flow(float *out, const float *depth, long depth_n_stride, c
                           long out_n_stride, int inverse_depth, int normalize_flow, int gate, hipStream_t s);
 void launch_flow_to_depth(float *out, long out_n_stride, const float *flow, long flow_n_stride,
                           const float *intrinsics, const float *rotation, const float *translation, int N, int H,
-                          int W, int inverse_depth, int normalized_flow, int method, hipStream_t s);
+                          int W, int inverse_depth, int normalized_flow, int method, float clip_hi, hipStream_t s);
 void launch_warp2d(float *out, long out_n_stride, const float *in, long in_n_stride, const float *disp,
                    long disp_n_stride, int N, int C, int H, int W, int normalized, int border_mode,
                    float border_value, hipStream_t s);

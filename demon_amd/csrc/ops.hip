@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void flow_to_depth_kernel(float *__restrict__ 
                                                             const float *__restrict__ intrinsics,
                                                             const float *__restrict__ rotation,
                                                             const float *__restrict__ translation, int H, int W,
-                                                            int inverse_depth, int normalized_flow, int method)
+                                                            int inverse_depth, int normalized_flow, int method,
+                                                            float clip_hi)
 {
     const int n = blockIdx.y;
     const int hw = H * W;
@@ -179,7 +180,11 @@ __global__ __launch_bounds__(256) void flow_to_depth_kernel(float *__restrict__ 
         const float ay = fy * qy - (p2y - cy) * qz, by = (p2y - cy) * t[2] - fy * t[1];
         z = (ax * bx + ay * by) / (ax * ax + ay * ay);
     }
-    out[(long)n * out_n_stride + idx] = inverse_depth ? 1.0f / z : z;
+    float r = inverse_depth ? 1.0f / z : z;
+    // v2/blocks.py:379 tf.clip_by_value(., 0, 50) fused here (clip_hi > 0): max(min(r, hi), 0) with fminf / fmaxf, i.e. the
+    // semantics of TF's GPU kernels, the only backend the v2 driver accepts (example_v2.py:50-54): NaN -> hi
+    if (clip_hi > 0.0f) r = fmaxf(fminf(r, clip_hi), 0.0f);
+    out[(long)n * out_n_stride + idx] = r;
 }
 
 // Backward bilinear warp, direct gather (default, see launch_warp2d).  grid: (ceil(H*W/256), N); each thread handles one
@@ -480,11 +485,11 @@ void launch_depth_to_flow(float *out, const float *depth, long depth_n_stride, c
 
 void launch_flow_to_depth(float *out, long out_n_stride, const float *flow, long flow_n_stride,
                           const float *intrinsics, const float *rotation, const float *translation, int N, int H,
-                          int W, int inverse_depth, int normalized_flow, int method, hipStream_t s)
+                          int W, int inverse_depth, int normalized_flow, int method, float clip_hi, hipStream_t s)
 {
     dim3 grid((H * W + 255) / 256, N);
     hipLaunchKernelGGL(flow_to_depth_kernel, grid, dim3(256), 0, s, out, out_n_stride, flow, flow_n_stride, intrinsics,
-                       rotation, translation, H, W, inverse_depth, normalized_flow, method);
+                       rotation, translation, H, W, inverse_depth, normalized_flow, method, clip_hi);
 }
 
 void launch_warp2d(float *out, long out_n_stride, const float *in, long in_n_stride, const float *disp,

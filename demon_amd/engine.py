@@ -26,10 +26,15 @@ class DemonContext:
     OUTPUT_KEYS = ("predict_flow5", "predict_conf5", "predict_flow2", "predict_conf2", "predict_depth2",
                    "predict_normal2", "predict_rotation", "predict_translation", "predict_scale")
 
-    def __init__(self, device=0, max_batch=1, height=192, width=256):
+    def __init__(self, device=0, max_batch=1, height=192, width=256, version=1):
+        """version 1: networks_original.py / blocks_original.py; version 2: v2/networks.py / v2/blocks.py"""
+        if version not in (1, 2):
+            raise DemonError("version must be 1 (original) or 2 (v2)")
         self.lib = _lib.load()
         self.h = ctypes.c_void_p()
-        rc = self.lib.demon_create(ctypes.byref(self.h), device, max_batch, height, width)
+        self.version = version
+        create = self.lib.demon_create if version == 1 else self.lib.demon_create_v2
+        rc = create(ctypes.byref(self.h), device, max_batch, height, width)
         if rc != 0:
             raise DemonError("demon_create failed (%d): %s" % (rc, self.lib.demon_last_error(None).decode()))
         self.device, self.max_batch, self.H, self.W = device, max_batch, height, width
@@ -108,7 +113,8 @@ class DemonContext:
         import json
         import os
         directory = directory or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
-        path = os.path.join(directory, "plan_%dx%d_n%d.json" % (self.H, self.W, int(n)))
+        tag = "" if self.version == 1 else "v2_"
+        path = os.path.join(directory, "plan_%s%dx%d_n%d.json" % (tag, self.H, self.W, int(n)))
         if not os.path.exists(path):
             return False
         with open(path) as f:
@@ -157,7 +163,15 @@ class DemonContext:
         depth2 = _f32(depth2, (n, 1, self.h2, self.w2), "depth2")
         d0 = np.empty((n, 1, self.H, self.W), np.float32)
         self._check(self.lib.demon_refine(self.h, n, _fp(image1), _fp(depth2), _fp(d0)))
-        return {"predict_depth0": d0}
+        out = {"predict_depth0": d0}
+        self._add_normal0(out, n)
+        return out
+
+    def _add_normal0(self, out, n):
+        if self.version == 2:   # v2/networks.py:223-226
+            n0 = np.empty((n, 3, self.H, self.W), np.float32)
+            self._check(self.lib.demon_download_normal0(self.h, n, _fp(n0)))
+            out["predict_normal0"] = n0
 
     def full(self, image_pair, image2_2, iterations=3):
         n = int(np.shape(image_pair)[0])
@@ -167,6 +181,7 @@ class DemonContext:
         d0 = np.empty((n, 1, self.H, self.W), np.float32)
         self._check(self.lib.demon_full(self.h, n, _fp(image_pair), _fp(image2_2), iterations, ctypes.byref(o), _fp(d0)))
         arrays["predict_depth0"] = d0
+        self._add_normal0(arrays, n)
         return arrays
 
     # ---- device-resident path -----------------------------------------------------------------------------
@@ -192,6 +207,7 @@ class DemonContext:
         self._check(self.lib.demon_download_outputs(self.h, n, ctypes.byref(o), _fp(d0) if with_depth0 else None))
         if with_depth0:
             arrays["predict_depth0"] = d0
+            self._add_normal0(arrays, n)
         return arrays
 
     def time_full(self, n, iterations, steps):
@@ -272,17 +288,24 @@ class DemonContext:
         return out
 
     # ---- single layers (TF weight layouts) ----------------------------------------------------------------
-    def conv2d(self, x, w_hwio, bias, stride=(1, 1), lrelu=False):
+    def conv2d(self, x, w_hwio, bias, stride=(1, 1), lrelu=False, padding="caffe"):
+        """padding 'caffe': k//2 zeros on both sides then VALID (helpers.py:70-94); 'same': tf.layers.conv2d(padding='same')
+        (v2/helpers.py:24-35)"""
         x, w_hwio, bias = _f32(x), _f32(w_hwio), _f32(bias)
         n, cin, h, w = x.shape
         kh, kw, ci, cout = w_hwio.shape
         if ci != cin or bias.shape != (cout,):
             raise DemonError("conv2d: weight / bias shape mismatch")
         sh, sw = stride
-        ho, wo = (h + 2 * (kh // 2) - kh) // sh + 1, (w + 2 * (kw // 2) - kw) // sw + 1
+        if padding == "same":
+            ho, wo, ph, pw = -(-h // sh), -(-w // sw), -1, -1
+        elif padding == "caffe":
+            ho, wo, ph, pw = (h + 2 * (kh // 2) - kh) // sh + 1, (w + 2 * (kw // 2) - kw) // sw + 1, kh // 2, kw // 2
+        else:
+            raise DemonError("padding must be 'caffe' or 'same'")
         out = np.empty((n, cout, ho, wo), np.float32)
         self._check(self.lib.demon_op_conv2d(self.h, _fp(out), _fp(x), _fp(w_hwio), _fp(bias), n, cin, h, w, cout, kh, kw,
-                                             sh, sw, kh // 2, kw // 2, int(lrelu)))
+                                             sh, sw, ph, pw, int(lrelu)))
         return out
 
     def deconv4x4s2(self, x, w_hwoi, bias, lrelu=False):

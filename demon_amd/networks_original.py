@@ -29,13 +29,15 @@ def _from_nchw(a, data_format):
 
 
 class _Net:
+    _version = 1
+
     def __init__(self, session, data_format="channels_first", batch_size=1):
         if data_format not in ("channels_first", "channels_last"):
             raise ValueError("data_format must be 'channels_first' or 'channels_last'")
         self.session = session
         self.data_format = data_format
         self.batch_size = batch_size
-        self._ctx = runtime.get_context(batch_size, _H, _W)
+        self._ctx = runtime.get_context(batch_size, _H, _W, version=self._version)
         w = getattr(session, "demon_weights", None)
         if w is not None:
             self._ctx.set_weights(w)

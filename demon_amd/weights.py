@@ -58,21 +58,80 @@ def _refine_net(scope="netRefine"):
             (scope + "/predict_depth0/conv1", (3, 3, 64, 16)), (scope + "/predict_depth0/conv2", (3, 3, 16, 1))]
 
 
-def layer_table(height=192, width=256):
-    """[(layer_name, kernel_shape)] for all 121 layers."""
-    fc_in = 128 * (height // 32) * (width // 32)  # 6144 at 192x256 (blocks_original.py:380-396)
+# ---- v2 (python/depthmotionnet/v2/blocks.py) ------------------------------------------------------------
+def _sep2(scope, name, cin, cout, k):
+    # v2/helpers.py:44-91: num_outputs may be (outputs of the k x 1 filter, outputs of the 1 x k filter)
+    cy, cx = cout if isinstance(cout, tuple) else (cout, cout)
+    return [("%s/%sy" % (scope, name), (k, 1, cin, cy)), ("%s/%sx" % (scope, name), (1, k, cy, cx))]
+
+
+def _encoder_v2(scope, conv2_out, extra_in, conv5_k, hw5):
+    # v2/blocks.py:141-213 (flow), :344-411 (depth+motion)
+    v = _sep2(scope, "conv1", 6, (24, 32), 9) + _sep2(scope, "conv2", 32, conv2_out, 7)
+    if extra_in:
+        v += _sep2(scope, "conv2_extra_inputs", extra_in, 32, 3)
+    v += _sep2(scope, "conv2_1", 64, 64, 3)
+    v += _sep2(scope, "conv3", 64, (96, 128), 5) + _sep2(scope, "conv3_1", 128, 128, 3)
+    v += _sep2(scope, "conv4", 128, (192, 256), 5) + _sep2(scope, "conv4_1", 256, 256, 3)
+    v += _sep2(scope, "conv5", 256, 384, conv5_k) + _sep2(scope, "conv5_1", 384, 384, 3)
+    v += [(scope + "/dense5", (96 * hw5, 96 * hw5))]
+    return v
+
+
+def _flow_net_v2(scope, iterative, hw5):
+    # v2/blocks.py:120-253
+    v = _encoder_v2(scope, 32 if iterative else (48, 64), 9 if iterative else 0, 5, hw5)
+    v += [(scope + "/predict_flow5/conv1", (3, 3, 480, 24)), (scope + "/predict_flow5/conv2", (3, 3, 24, 4)),
+          (scope + "/upsample_flow5to4/upconv", (4, 4, 2, 4)),
+          (scope + "/refine4/upconv", (4, 4, 256, 480)), (scope + "/refine3/upconv", (4, 4, 128, 514)),
+          (scope + "/refine2/upconv", (4, 4, 64, 256)),
+          (scope + "/predict_flow2/conv1", (3, 3, 128, 24)), (scope + "/predict_flow2/conv2", (3, 3, 24, 4))]
+    return v
+
+
+def _dm_net_v2(scope, iterative, hw5):
+    # v2/blocks.py:317-494
+    v = _encoder_v2(scope, 32, 8 if iterative else 7, 3, hw5)
+    v += _sep2(scope, "motion_conv3", 64, 64, 5) + _sep2(scope, "motion_conv4", 64, 64, 5)
+    v += _sep2(scope, "motion_conv5a", 64, 64, 3)
+    v += [(scope + "/motion_conv5b", (3, 3, 480, 64)), (scope + "/motion_fc1", (128 * hw5, 1024)),
+          (scope + "/motion_fc2", (1024, 128)), (scope + "/motion_fc3", (128, 7)),
+          (scope + "/refine4/upconv", (4, 4, 256, 384)), (scope + "/refine3/upconv", (4, 4, 128, 512)),
+          (scope + "/refine2/upconv", (4, 4, 64, 256)),
+          (scope + "/predict_depthnormal2/conv1", (3, 3, 128, 24)),
+          (scope + "/predict_depthnormal2/conv2", (3, 3, 24, 4))]
+    return v
+
+
+def _refine_net_v2(scope="netRefine"):
+    # v2/blocks.py:499-562: as the original but the head predicts depth + normal (4 channels)
+    return _refine_net(scope)[:-1] + [(scope + "/predict_depth0/conv2", (3, 3, 16, 4))]
+
+
+def layer_table(height=192, width=256, version=1):
+    """[(layer_name, kernel_shape)]: 121 layers for the original model, 137 for v2."""
+    hw5 = (height // 32) * (width // 32)
+    if version == 2:
+        return (_flow_net_v2("netFlow1", False, hw5) + _dm_net_v2("netDM1", False, hw5) +
+                _flow_net_v2("netFlow2", True, hw5) + _dm_net_v2("netDM2", True, hw5) + _refine_net_v2())
+    fc_in = 128 * hw5  # 6144 at 192x256 (blocks_original.py:380-396)
     return (_flow_net("netFlow1", False) + _dm_net("netDM1", False, fc_in) + _flow_net("netFlow2", True) +
             _dm_net("netDM2", True, fc_in) + _refine_net())
+
+
+def weights_version(weights):
+    """2 if the dict holds the v2 model's variables (it has a dense5 layer), else 1."""
+    return 2 if "netFlow1/dense5/kernel" in weights else 1
 
 
 def _cout(name, shape):
     return shape[2] if name.endswith("upconv") else shape[-1]
 
 
-def variable_shapes(height=192, width=256):
-    """dict tf variable name -> shape (242 tensors, 45 753 883 floats at 192x256)."""
+def variable_shapes(height=192, width=256, version=1):
+    """dict tf variable name -> shape (original: 242 tensors, 45 753 883 floats at 192x256)."""
     out = {}
-    for name, shape in layer_table(height, width):
+    for name, shape in layer_table(height, width, version):
         out[name + "/kernel"] = tuple(shape)
         out[name + "/bias"] = (_cout(name, shape),)
     return out
@@ -82,7 +141,7 @@ _LINEAR = ("predict_flow5/conv2", "predict_flow2/conv2", "predict_depthnormal2/c
            "upsample_flow5to4/upconv", "motion_fc3")
 
 
-def synthetic_weights(seed=1, height=192, width=256, head_scale=0.1):
+def synthetic_weights(seed=1, height=192, width=256, head_scale=0.1, version=1):
     """Deterministic random weights that keep the nets in their working regime.
 
     kernels ~ N(0, 2/fan_in) (He, the reference's variance_scaling_initializer, helpers.py:66-67), with the
@@ -94,7 +153,7 @@ def synthetic_weights(seed=1, height=192, width=256, head_scale=0.1):
     """
     rng = np.random.default_rng(seed)
     w = {}
-    for name, shape in layer_table(height, width):
+    for name, shape in layer_table(height, width, version):
         if name.endswith("upconv"):
             fan_in = 4 * shape[3]
         elif len(shape) == 2:

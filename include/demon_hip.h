@@ -54,6 +54,12 @@ typedef struct demon_outputs {
  * (examples/example.py:70-77; networks_original.py:23, :93, :204).  height/width must be multiples
  * of 32; 192x256 is the reference's fixed size (networks_original.py:38-42).                      */
 int demon_create(demon_ctx **ctx, int device, int max_batch, int height, int width);
+/* The retrained "v2" model: python/depthmotionnet/v2/networks.py:20-36, :80-122, :181-205 over v2/blocks.py (padding='same',
+ * (24,32)/(48,64)/(96,128)/(192,256) separable pairs, 384 channels at level 5, dense5 bottleneck, motion_conv3..5b branch,
+ * flow_to_depth2 + clip [0,50], predict_normal0).  Every other entry point works on such a context unchanged; the variable table
+ * (demon_variable_info) is the v2 one.  demon_variant returns 1 or 2.                                                        */
+int demon_create_v2(demon_ctx **ctx, int device, int max_batch, int height, int width);
+int demon_variant(const demon_ctx *ctx);
 int demon_destroy(demon_ctx *ctx);
 const char *demon_last_error(const demon_ctx *ctx); /* ctx may be NULL: error of a failed create */
 int demon_device(const demon_ctx *ctx);
@@ -107,6 +113,8 @@ int demon_run_full(demon_ctx *ctx, int n, int iterations);
 int demon_run_bootstrap(demon_ctx *ctx, int n);
 int demon_synchronize(demon_ctx *ctx);
 int demon_download_outputs(demon_ctx *ctx, int n, const demon_outputs *out, float *predict_depth0);
+/* v2 contexts only: predict_normal0 [n,3,H,W] of the last refinement run (v2/networks.py:223-226; v2/blocks.py:560-562). */
+int demon_download_normal0(demon_ctx *ctx, int n, float *predict_normal0);
 /* time `steps` back-to-back demon_run_full calls with hip events on the context stream */
 int demon_time_full(demon_ctx *ctx, int n, int iterations, int steps, float *total_ms);
 
@@ -146,7 +154,9 @@ int demon_op_median3x3_downsample(demon_ctx *ctx, float *out, const float *in, i
 
 /* ---- layer-level entry points (host buffers; TF weight layouts) -------------------------------------
  * Replace the tf.layers calls of helpers.py:85-94 / :128-153 (conv2d on a zero padded input),
- * blocks_original.py:64-75 / :97-110 (conv2d_transpose k4 s2 + crop) and :390-410 (dense).        */
+ * blocks_original.py:64-75 / :97-110 (conv2d_transpose k4 s2 + crop) and :390-410 (dense).
+ * conv2d: ph, pw = kh/2, kw/2 (zeros on both sides, then VALID), or ph = pw = -1 for padding='same' of v2/helpers.py:24-35
+ * (out = ceil(n/s), pad_total/2 zeros in front).                                                    */
 int demon_op_conv2d(demon_ctx *ctx, float *out, const float *in, const float *w_hwio, const float *bias, int n,
                     int cin, int h, int w, int cout, int kh, int kw, int sh, int sw, int ph, int pw, int lrelu);
 int demon_op_deconv4x4s2(demon_ctx *ctx, float *out, const float *in, const float *w_hwoi, const float *bias,

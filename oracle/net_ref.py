@@ -12,6 +12,10 @@ C loops in oracle/demon_oracle.c (tests/test_oracle.py).  lmbspecialops calls go
 weights: dict  TF variable name -> numpy array in TF layout
    conv   '<scope>/<name>/kernel' [kh,kw,Cin,Cout], deconv [4,4,Cout,Cin], dense [in,out], '.../bias' [Cout]
 All activations are NCHW ('channels_first'); the API edge converts for 'channels_last'.
+
+The v2 model (python/depthmotionnet/v2/blocks.py, v2/helpers.py, v2/networks.py) is restated below the
+original one: the same Net helper with TensorFlow's padding='same' rule written out in full
+(out = ceil(n / s); pad_total = max((out - 1) * s + k - n, 0); pad_before = pad_total // 2).
 """
 import numpy as np
 import torch
@@ -34,10 +38,21 @@ def lrelu(x):
 class Net:
     """Holds the torch-layout weights of one variable scope ('netFlow1', ...)."""
 
-    def __init__(self, weights, scope):
+    def __init__(self, weights, scope, same=False):
         self.w = weights
         self.scope = scope
+        self.same = same     # False: helpers.py caffe padding; True: v2/helpers.py padding='same'
         self._cache = {}
+
+    def _pad(self, x, kh, kw, sh, sw):
+        if not self.same:
+            return F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2))
+        pads = []
+        for n, k, s in ((x.shape[3], kw, sw), (x.shape[2], kh, sh)):   # F.pad order: W first
+            out = -(-n // s)
+            total = max((out - 1) * s + k - n, 0)
+            pads += [total // 2, total - total // 2]
+        return F.pad(x, tuple(pads))
 
     def _conv_w(self, name):
         key = ("c", name)
@@ -64,17 +79,15 @@ class Net:
     def conv(self, x, name, stride=1, act=True):
         w, b = self._conv_w(name)
         kh, kw = w.shape[2], w.shape[3]
-        x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2))
-        y = F.conv2d(x, w, b, stride=stride)
+        y = F.conv2d(self._pad(x, kh, kw, stride, stride), w, b, stride=stride)
         return lrelu(y) if act else y
 
     # helpers.py:105-153: k x 1 (stride (s,1)) then 1 x k (stride (1,s)), both leaky relu
     def conv2(self, x, name, k, stride):
         wy, by = self._conv_w(name + "y")
         wx, bx = self._conv_w(name + "x")
-        p = k // 2
-        t = lrelu(F.conv2d(F.pad(x, (0, 0, p, p)), wy, by, stride=(stride, 1)))
-        return lrelu(F.conv2d(F.pad(t, (p, p, 0, 0)), wx, bx, stride=(1, stride)))
+        t = lrelu(F.conv2d(self._pad(x, k, 1, stride, 1), wy, by, stride=(stride, 1)))
+        return lrelu(F.conv2d(self._pad(t, 1, k, 1, stride), wx, bx, stride=(1, stride)))
 
     # blocks_original.py:97-110: deconv k4 s2 VALID, activation, crop 1 -> padding=1 in torch
     # blocks_original.py:64-75 ('same', linear) has the same geometry
@@ -221,3 +234,120 @@ class DemonRef:
             "predict_translation": dm["predict_translation"].numpy(),
             "predict_scale": dm["predict_scale"].numpy(),
         }
+
+
+# ======================================================================================================
+# v2 model: python/depthmotionnet/v2/blocks.py
+# ======================================================================================================
+def _dense5(net, conv5_1):
+    """v2/blocks.py:197-213, :395-411: first 96 channels, flattened C,H,W, square dense + lrelu, back as 96 channels."""
+    n, _, h, w = conv5_1.shape
+    d = net.dense(conv5_1[:, 0:96].reshape(n, -1), "dense5")
+    return torch.cat((conv5_1, d.reshape(n, 96, h, w)), 1)
+
+
+def flow_block_v2(net, image_pair, image2_2=None, prev=None):
+    """v2/blocks.py:120-253."""
+    conv1 = net.conv2(image_pair, "conv1", 9, 2)
+    if prev is None:
+        conv2 = net.conv2(conv1, "conv2", 7, 2)
+        conv2_1 = net.conv2(conv2, "conv2_1", 3, 1)
+    else:
+        conv2 = net.conv2(conv1, "conv2", 7, 2)
+        flow = ops_ref.depth_to_flow(prev["depth2"].numpy(), INTRINSICS, prev["rotation"].numpy(),
+                                     prev["translation"].numpy(), inverse_depth=True, normalize_flow=True,
+                                     gate=True)          # :155-168
+        warped = ops_ref.warp2d(image2_2.numpy(), flow, normalized=True, border_mode="value")  # :171-176
+        extra = torch.cat((_t(warped), _t(flow), prev["depth2"], prev["normal2"]), 1)          # :180-183
+        conv_extra = net.conv2(extra, "conv2_extra_inputs", 3, 1)
+        conv2_1 = net.conv2(torch.cat((conv2, conv_extra), 1), "conv2_1", 3, 1)                # :186-187
+    conv3_1 = net.conv2(net.conv2(conv2_1, "conv3", 5, 2), "conv3_1", 3, 1)
+    conv4_1 = net.conv2(net.conv2(conv3_1, "conv4", 5, 2), "conv4_1", 3, 1)
+    conv5_1 = net.conv2(net.conv2(conv4_1, "conv5", 5, 2), "conv5_1", 3, 1)
+    feat5 = _dense5(net, conv5_1)
+    flowconf5 = net.conv(net.conv(feat5, "predict_flow5/conv1"), "predict_flow5/conv2", act=False)
+    up5to4 = net.deconv(flowconf5, "upsample_flow5to4/upconv", act=False)
+    concat4 = torch.cat((net.deconv(feat5, "refine4/upconv"), conv4_1, up5to4), 1)             # :110-116 order
+    concat3 = torch.cat((net.deconv(concat4, "refine3/upconv"), conv3_1), 1)
+    concat2 = torch.cat((net.deconv(concat3, "refine2/upconv"), conv2_1), 1)
+    flowconf2 = net.conv(net.conv(concat2, "predict_flow2/conv1"), "predict_flow2/conv2", act=False)
+    return {"predict_flowconf5": flowconf5, "predict_flowconf2": flowconf2}
+
+
+def depthmotion_block_v2(net, image_pair, image2_2, flowconf2, prev_rt=None):
+    """v2/blocks.py:317-494."""
+    conv1 = net.conv2(image_pair, "conv1", 9, 2)
+    conv2 = net.conv2(conv1, "conv2", 7, 2)
+    flow2 = flowconf2[:, 0:2].contiguous()
+    warped = ops_ref.warp2d(image2_2.numpy(), flow2.numpy(), normalized=True, border_mode="value")  # :351
+    extra = [_t(warped), flowconf2]
+    if prev_rt is not None:
+        d = ops_ref.flow_to_depth2(flow2.numpy(), INTRINSICS, prev_rt[0].numpy(), prev_rt[1].numpy(),
+                                   inverse_depth=True, normalized_flow=True)                    # :362-369
+        # :379 clip_by_value(0, 50) = max(min(x, 50), 0); NaN -> 50 as with the fminf / fmaxf of TF's GPU kernels
+        extra.append(_t(np.fmax(np.fmin(d, np.float32(50.0)), np.float32(0.0))))
+    conv_extra = net.conv2(torch.cat(extra, 1), "conv2_extra_inputs", 3, 1)
+    conv2_1 = net.conv2(torch.cat((conv2, conv_extra), 1), "conv2_1", 3, 1)
+    conv3_1 = net.conv2(net.conv2(conv2_1, "conv3", 5, 2), "conv3_1", 3, 1)
+    conv4_1 = net.conv2(net.conv2(conv3_1, "conv4", 5, 2), "conv4_1", 3, 1)
+    conv5_1 = net.conv2(net.conv2(conv4_1, "conv5", 3, 2), "conv5_1", 3, 1)                     # k=3 (:392)
+    feat5 = _dense5(net, conv5_1)
+    m = net.conv2(net.conv2(conv2_1, "motion_conv3", 5, 2), "motion_conv4", 5, 2)               # :414-415
+    m5a = net.conv2(m, "motion_conv5a", 3, 2)
+    m5b = net.conv(feat5, "motion_conv5b")
+    fc = torch.cat((m5a, m5b), 1)
+    fc = fc.reshape(fc.shape[0], -1)                                                           # :431
+    fc = net.dense(net.dense(fc, "motion_fc1"), "motion_fc2")
+    motion = net.dense(fc, "motion_fc3", act=False)
+    rotation, translation, scale = motion[:, 0:3], motion[:, 3:6], motion[:, 6:7]               # :457
+    concat4 = torch.cat((net.deconv(conv5_1, "refine4/upconv"), conv4_1), 1)                    # conv5_1, not feat5 (:462)
+    concat3 = torch.cat((net.deconv(concat4, "refine3/upconv"), conv3_1), 1)
+    concat2 = torch.cat((net.deconv(concat3, "refine2/upconv"), conv2_1), 1)
+    dn = net.conv(net.conv(concat2, "predict_depthnormal2/conv1"), "predict_depthnormal2/conv2", act=False)
+    depth = scale.reshape(-1, 1, 1, 1) * dn[:, 0:1]                                             # :294-300
+    return {"predict_depth2": depth.contiguous(), "predict_normal2": dn[:, 1:4].contiguous(),
+            "predict_rotation": rotation.contiguous(), "predict_translation": translation.contiguous(),
+            "predict_scale": scale.contiguous()}
+
+
+def refine_block_v2(net, image1, depth2):
+    """v2/blocks.py:499-562."""
+    H, W = image1.shape[2], image1.shape[3]
+    up = _t(ops_ref.resize_nearest(depth2.numpy(), H, W))
+    x = torch.cat((image1, up), 1)
+    conv0 = net.conv(x, "conv0")
+    conv1_1 = net.conv(net.conv(conv0, "conv1", stride=2), "conv1_1")
+    conv2_1 = net.conv(net.conv(conv1_1, "conv2", stride=2), "conv2_1")
+    concat1 = torch.cat((net.deconv(conv2_1, "refine1/upconv"), conv1_1), 1)
+    concat0 = torch.cat((net.deconv(concat1, "refine0/upconv"), conv0), 1)
+    dn = net.conv(net.conv(concat0, "predict_depth0/conv1"), "predict_depth0/conv2", act=False)
+    return {"predict_depth0": dn[:, 0:1].contiguous(), "predict_normal0": dn[:, 1:4].contiguous()}
+
+
+class DemonRefV2(DemonRef):
+    """The v2 sub-nets with the stage order of examples/example_v2.py:93-105."""
+
+    def __init__(self, weights):
+        self.nets = {s: Net(weights, s, same=True) for s in ("netFlow1", "netDM1", "netFlow2", "netDM2", "netRefine")}
+
+    @torch.no_grad()
+    def bootstrap(self, image_pair, image2_2):
+        image_pair, image2_2 = _t(image_pair), _t(image2_2)
+        f = flow_block_v2(self.nets["netFlow1"], image_pair)
+        dm = depthmotion_block_v2(self.nets["netDM1"], image_pair, image2_2, f["predict_flowconf2"])
+        return self._pack(f, dm)
+
+    @torch.no_grad()
+    def iterative(self, image_pair, image2_2, depth2, normal2, rotation, translation):
+        image_pair, image2_2 = _t(image_pair), _t(image2_2)
+        prev = {"depth2": _t(depth2), "normal2": _t(normal2), "rotation": _t(rotation),
+                "translation": _t(translation)}
+        f = flow_block_v2(self.nets["netFlow2"], image_pair, image2_2, prev)
+        dm = depthmotion_block_v2(self.nets["netDM2"], image_pair, image2_2, f["predict_flowconf2"],
+                                  (prev["rotation"], prev["translation"]))
+        return self._pack(f, dm)
+
+    @torch.no_grad()
+    def refine(self, image1, depth2):
+        r = refine_block_v2(self.nets["netRefine"], _t(image1), _t(depth2))
+        return {k: v.numpy() for k, v in r.items()}

@@ -127,6 +127,20 @@ def conv2d_hwio(x, w, b, stride, pad, lrelu):
     return out
 
 
+def conv2d_hwio_same(x, w, b, stride, lrelu):
+    """tf.layers.conv2d(padding='same') (v2/helpers.py:24-35) by the naive loops: the input is zero-padded explicitly with
+    TensorFlow's rule (out = ceil(n/s); pad_total = max((out-1)*s + k - n, 0); pad_total // 2 in front) and convolved VALID."""
+    x = np.asarray(x, np.float32)
+    kh, kw = w.shape[0], w.shape[1]
+    pads = []
+    for n, k, s in ((x.shape[2], kh, stride[0]), (x.shape[3], kw, stride[1])):
+        out = -(-n // s)
+        total = max((out - 1) * s + k - n, 0)
+        pads.append((total // 2, total - total // 2))
+    xp = np.pad(x, ((0, 0), (0, 0), pads[0], pads[1]))
+    return conv2d_hwio(xp, w, b, stride, (0, 0), lrelu)
+
+
 def deconv4x4s2_crop(x, w, b, lrelu):
     x, px = _f(x)
     w, pw = _f(w)

@@ -222,3 +222,48 @@ def test_full_pipeline_shapes_and_regime(synth_weights):
     for k, v in r.items():
         assert np.isfinite(v).all(), k
     assert (r["predict_depth2"] > 0).mean() > 0.5
+
+
+# ---- v2 model (python/depthmotionnet/v2) ------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [(9, 2), (7, 2), (5, 2), (3, 2), (3, 1)])
+def test_v2_same_padding_separable_pair_matches_naive_c(cfg):
+    """Net(same=True).conv2 (torch) == the naive C loops on an explicitly 'same'-padded input (v2/helpers.py:44-91),
+    and the stride-2 cases differ from the caffe padding of the original model (the zeros sit asymmetrically)."""
+    k, s = cfg
+    rng = np.random.default_rng(20)
+    x = rng.standard_normal((2, 5, 12, 16)).astype(np.float32)
+    w = {"n/cy/kernel": rng.standard_normal((k, 1, 5, 6)).astype(np.float32), "n/cy/bias": rng.standard_normal(6).astype(np.float32),
+         "n/cx/kernel": rng.standard_normal((1, k, 6, 7)).astype(np.float32), "n/cx/bias": rng.standard_normal(7).astype(np.float32)}
+    import torch
+    got = net_ref.Net(w, "n", same=True).conv2(torch.from_numpy(x), "c", k, s).numpy()
+    mid = ops_ref.conv2d_hwio_same(x, w["n/cy/kernel"], w["n/cy/bias"], (s, 1), True)
+    want = ops_ref.conv2d_hwio_same(mid, w["n/cx/kernel"], w["n/cx/bias"], (1, s), True)
+    assert got.shape == want.shape == (2, 7, 12 // s, 16 // s)
+    assert rel_l1(got, want) < 1e-5
+    caffe = net_ref.Net(w, "n", same=False).conv2(torch.from_numpy(x), "c", k, s).numpy()
+    if s == 2:
+        assert rel_l1(caffe, want) > 1e-2
+    else:
+        assert rel_l1(caffe, want) < 1e-5
+
+
+def test_v2_variable_table_and_oracle_forward():
+    """v2 variable set (v2/blocks.py) and one full oracle pass at 64x96: shapes and keys of v2/networks.py:59-66, :223-226"""
+    from demon_amd import weights
+    shapes = weights.variable_shapes(version=2)
+    assert len(shapes) == 2 * 137
+    assert shapes["netFlow1/conv1y/kernel"] == (9, 1, 6, 24) and shapes["netFlow1/conv1x/kernel"] == (1, 9, 24, 32)
+    assert shapes["netFlow1/conv2y/kernel"] == (7, 1, 32, 48) and shapes["netFlow2/conv2x/kernel"] == (1, 7, 32, 32)
+    assert shapes["netDM2/conv5y/kernel"] == (3, 1, 256, 384) and shapes["netFlow2/conv5y/kernel"] == (5, 1, 256, 384)
+    assert shapes["netDM1/dense5/kernel"] == (4608, 4608)
+    assert shapes["netFlow1/refine4/upconv/kernel"] == (4, 4, 256, 480) and shapes["netDM1/refine4/upconv/kernel"] == (4, 4, 256, 384)
+    assert shapes["netDM2/motion_conv5b/kernel"] == (3, 3, 480, 64) and shapes["netDM2/motion_fc1/kernel"] == (6144, 1024)
+    assert shapes["netRefine/predict_depth0/conv2/kernel"] == (3, 3, 16, 4)
+    assert weights.weights_version(shapes) == 2 and weights.weights_version(weights.variable_shapes()) == 1
+    h, w = 64, 96
+    wts = weights.synthetic_weights(seed=3, height=h, width=w, version=2)
+    pair, img2_2 = make_inputs(1, h, w, seed=4)
+    r = net_ref.DemonRefV2(wts).full(pair, img2_2, iterations=1)
+    assert r["predict_depth0"].shape == (1, 1, h, w) and r["predict_normal0"].shape == (1, 3, h, w)
+    assert r["predict_flow5"].shape == (1, 2, h // 32, w // 32) and r["predict_depth2"].shape == (1, 1, h // 4, w // 4)
+    assert all(np.isfinite(v).all() for v in r.values())

@@ -12,18 +12,19 @@ ap.add_argument("--width", type=int, default=256)
 ap.add_argument("--batch", type=int, nargs="+", default=[32])
 ap.add_argument("--rounds", type=int, default=3, help="majority vote over this many autotune runs")
 ap.add_argument("--outdir", default="gpurun_out")
+ap.add_argument("--version", type=int, default=1, choices=[1, 2], help="1 = original model, 2 = v2 model")
 args = ap.parse_args()
 os.makedirs(args.outdir, exist_ok=True)
 for n in args.batch:
-    ctx = DemonContext(0, n, args.height, args.width)
+    ctx = DemonContext(0, n, args.height, args.width, version=args.version)
     votes = collections.defaultdict(collections.Counter)
     for _ in range(args.rounds):
         ctx.autotune(n)
         for layer, p in ctx.get_plan(n).items():
             votes[layer][tuple(p)] += 1
     plan = {layer: list(c.most_common(1)[0][0]) for layer, c in votes.items()}
-    path = os.path.join(args.outdir, "plan_%dx%d_n%d.json" % (args.height, args.width, n))
+    path = os.path.join(args.outdir, "plan_%s%dx%d_n%d.json" % ("" if args.version == 1 else "v2_", args.height, args.width, n))
     with open(path, "w") as f:
-        json.dump({"gpu": "MI355X (gfx950)", "height": args.height, "width": args.width, "batch": n, "plan": plan}, f, indent=0, sort_keys=True)
+        json.dump({"gpu": "MI355X (gfx950)", "model_version": args.version, "height": args.height, "width": args.width, "batch": n, "plan": plan}, f, indent=0, sort_keys=True)
     print(path, len(plan), "layers")
     ctx.close()
