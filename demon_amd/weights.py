@@ -141,7 +141,7 @@ _LINEAR = ("predict_flow5/conv2", "predict_flow2/conv2", "predict_depthnormal2/c
            "upsample_flow5to4/upconv", "motion_fc3")
 
 
-def synthetic_weights(seed=1, height=192, width=256, head_scale=0.1, version=1):
+def synthetic_weights(seed=1, height=192, width=256, head_scale=0.1, version=1, consistent_flow=None):
     """Deterministic random weights that keep the nets in their working regime.
 
     kernels ~ N(0, 2/fan_in) (He, the reference's variance_scaling_initializer, helpers.py:66-67), with the
@@ -150,7 +150,17 @@ def synthetic_weights(seed=1, height=192, width=256, head_scale=0.1, version=1):
     t = (0.8, 0.2, -0.1), scale = 1 and the depth head towards inverse depth 0.5 so that depth_to_flow /
     flow_to_depth see valid geometry (otherwise the NaN gate of blocks_original.py:163-168 would be all
     that is tested).  head_scale=1.0 gives the "gate stress" variant.
+
+    consistent_flow (default: on for version 2): the level-2 flow head is biased towards the flow that the biased motion and
+    depth imply (u ~ fx*tx*d = 0.356, v ~ fy*ty*d = 0.119, normalized).  The v2 depth+motion block feeds
+    clip(1 / flow_to_depth2(flow), 0, 50) to a conv (v2/blocks.py:362-381): where the triangulated depth passes through zero
+    the input jumps between 0 and 50, so with random flows the MODEL is chaotic -- a 1e-7 perturbation of the images moves the
+    oracle's own outputs by 1e-2 after three iterations -- and no implementation can be compared at 1e-3.  With flows that
+    agree with the motion the triangulated depth stays positive and the same perturbation moves the outputs by 1e-6.
+    consistent_flow=False gives the "clip stress" variant.
     """
+    if consistent_flow is None:
+        consistent_flow = version == 2
     rng = np.random.default_rng(seed)
     w = {}
     for name, shape in layer_table(height, width, version):
@@ -166,6 +176,8 @@ def synthetic_weights(seed=1, height=192, width=256, head_scale=0.1, version=1):
             k *= np.float32(head_scale)
         if name.endswith("motion_fc3"):
             b += np.array([0.0, 0.0, 0.0, 0.8, 0.2, -0.1, 1.0], np.float32)
+        if consistent_flow and name.endswith("predict_flow2/conv2"):
+            b[0:2] += np.array([0.356, 0.119], np.float32)
         if name.endswith("predict_depthnormal2/conv2"):
             b[0] += np.float32(0.5)
         if name.endswith("predict_depth0/conv2"):
