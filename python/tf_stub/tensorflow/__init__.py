@@ -1,5 +1,6 @@
-"""Minimal stand-in for the handful of TensorFlow-1 symbols that the reference driver examples/example.py touches
-(:45, :70-72, :79, :82-83), so that the unmodified script runs on the MI355X-native path without TensorFlow:
+"""Minimal stand-in for the handful of TensorFlow-1 symbols that the reference drivers examples/example.py (:45, :70-72, :79,
+:82-83) and examples/example_v2.py (:50, :76-78, :85, :88-89) touch, so that the unmodified scripts run on the MI355X-native
+path without TensorFlow:
 
     PYTHONPATH=<repo>/python/tf_stub:<repo>/python  MPLBACKEND=Agg  python <reference>/examples/example.py
 
@@ -63,16 +64,17 @@ class _Saver:
     def restore(self, session, save_path):
         import demon_amd
         from demon_amd import weights as W
-        names = list(W.variable_shapes())
         if os.path.exists(save_path + ".index"):
-            from demon_amd.tf_checkpoint import load_tf_checkpoint
-            w = load_tf_checkpoint(save_path, names)
+            from demon_amd.tf_checkpoint import load_tf_checkpoint, read_index
+            # original model (example.py) or v2 model (example_v2.py --checkpoint): told apart by the dense5 layer
+            version = 2 if "netFlow1/dense5/kernel" in read_index(save_path)[0] else 1
+            w = load_tf_checkpoint(save_path, list(W.variable_shapes(version=version)))
         elif os.path.exists(save_path + ".npz"):
             w = W.load_npz(save_path + ".npz")
-        elif os.environ.get("DEMON_SYNTHETIC_WEIGHTS") == "1":
-            w = W.synthetic_weights(seed=1)
+        elif os.environ.get("DEMON_SYNTHETIC_WEIGHTS") in ("1", "2"):
+            w = W.synthetic_weights(seed=1, version=int(os.environ["DEMON_SYNTHETIC_WEIGHTS"]))
         else:
-            raise IOError("checkpoint %s(.index|.npz) not found (set DEMON_SYNTHETIC_WEIGHTS=1 for random weights)" % save_path)
+            raise IOError("checkpoint %s(.index|.npz) not found (set DEMON_SYNTHETIC_WEIGHTS=1 / =2 for random weights of the original / v2 model)" % save_path)
         session.demon_weights = w
         demon_amd.set_default_weights(w)  # networks constructed before restore() pick the weights up here
 

@@ -84,6 +84,15 @@ def test_tensorflow_stub_restores_weights(tmp_path):
         assert session.demon_weights["netDM2/motion_fc1/kernel"].shape == (6144, 1024)
         with pytest.raises(IOError):
             tf.train.Saver().restore(session, str(tmp_path / "nope"))
+        # a checkpoint of the v2 model (example_v2.py:88-89) is recognised by its dense5 layer
+        w2 = {k: np.full(s, 0.5, np.float32) for k, s in W.variable_shapes(version=2).items()}
+        prefix2 = str(tmp_path / "demon_v2")
+        ck.save_tf_checkpoint(prefix2, w2)
+        session2 = tf.InteractiveSession()
+        tf.train.Saver().restore(session2, prefix2)
+        assert set(session2.demon_weights) == set(w2)
+        assert session2.demon_weights["netFlow2/dense5/kernel"].shape == (4608, 4608)
+        assert demon_amd.default_weights(2) is session2.demon_weights and demon_amd.default_weights(1) is session.demon_weights
     finally:
         sys.path.remove(os.path.join(ROOT, "python", "tf_stub"))
         sys.modules.pop("tensorflow", None)
