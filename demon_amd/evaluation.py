@@ -118,6 +118,25 @@ def depth_errors(pred, gt):
             "a3": ratio_threshold(p, g, 1.25 ** 3), "pixels": int(m.sum())}
 
 
+def evaluate_depth(translation_gt, depth_gt, depth_pred, inverse_gt=True, inverse_pred=True, depth_scaling="abs"):
+    """metrics.py:324-374: errors of the prediction on the commonly valid pixels, without and with the least-squares scale.
+    Inputs are inverse depths by default; the ground truth is divided by |translation_gt| when that is not 1.
+    Returns (errs, errs_pred_scaled) as dicts of depth_errors()."""
+    depth_gt, depth_pred = np.asarray(depth_gt), np.asarray(depth_pred)
+    m = valid_depth_mask(depth_pred, depth_gt)
+    p, g = depth_pred[m].astype(np.float64), depth_gt[m].astype(np.float64)
+    if inverse_gt:
+        g = 1.0 / g
+    if inverse_pred:
+        p = 1.0 / p
+    tn = float(np.sqrt(np.dot(translation_gt, translation_gt)))
+    if not np.isclose(1.0, tn):
+        g = g / tn
+    errs = depth_errors(p, g)
+    scale = depth_scale_factor(*[a[valid_depth_mask(p, g)] for a in (p, g)], scaling=depth_scaling)
+    return errs, depth_errors(p * scale, g)
+
+
 # ---- motion metrics (metrics.py:390-445) -------------------------------------------------------------------------
 def _rotmat(aa):
     aa = np.asarray(aa, np.float64).reshape(3)
@@ -144,7 +163,9 @@ def motion_errors(pred_rotation, pred_translation, gt_rotation, gt_translation, 
 
 
 def flow_epe(flow1, flow2):
-    """mean end point error over pixels where both flows are finite (metrics.py:377-387); flows [2,H,W]"""
+    """mean end point error (metrics.py:377-387); flows [2,H,W].  The reference masks the error map with its depth validity
+    test, i.e. it averages over the pixels whose end point error is finite AND > 0."""
     f1, f2 = np.asarray(flow1, np.float64), np.asarray(flow2, np.float64)
-    m = np.isfinite(f1).all(0) & np.isfinite(f2).all(0)
-    return np.nan if not m.any() else np.sqrt(np.square(f1 - f2).sum(0))[m].mean()
+    epe = np.sqrt(np.square(f1 - f2).sum(0))
+    m = valid_depth_mask(epe)
+    return np.nan if not m.any() else epe[m].mean()

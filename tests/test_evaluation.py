@@ -35,6 +35,52 @@ def test_motion_metrics_known_answers():
     np.testing.assert_allclose(ev.flow_epe(f, g), 5.0)
 
 
+def test_metrics_match_reference_goldens():
+    """demon_amd.evaluation == the reference's own evaluation/metrics.py, run in the build container on the sculpture depth
+    maps the reference ships (tests/golden/make_golden_metrics.py -> metrics_golden.json; inputs regenerated from seeds)"""
+    import json
+    import os
+    import sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gdir)
+    try:
+        import make_golden_metrics as mk
+    finally:
+        sys.path.remove(gdir)
+    with open(os.path.join(gdir, "metrics_golden.json")) as f:
+        gold = json.load(f)
+    geo = np.load(os.path.join(gdir, "sculpture_geometry.npz"))   # holds the reference's sculpture_depth{1,2}.npy
+    names = {"a1": "ratio_threshold_1.25", "a2": "ratio_threshold_1.5625", "a3": "ratio_threshold_1.953125", "pixels": "num_valid"}
+
+    def check(mine, ref):
+        for k, v in mine.items():
+            want = ref[names.get(k, k)]
+            np.testing.assert_allclose(v, np.nan if want is None else want, rtol=2e-4, err_msg=k)   # reference sums in float32
+
+    it = iter(gold["evaluate_depth"])
+    for ci, (gt, pred, t) in enumerate(mk.cases(geo["depth1"], geo["depth2"])):
+        for scaling, inverse in (("abs", False), ("log", False), ("inv", False), ("abs", True)):
+            g = next(it)
+            assert g["scaling"] == scaling and g["inverse"] == inverse
+            e, es = ev.evaluate_depth(t, gt, pred, inverse_gt=inverse, inverse_pred=inverse, depth_scaling=scaling)
+            check(e, g["errs"])
+            check(es, g["errs_scaled"])
+        m = ev.valid_depth_mask(pred, gt)
+        for s_ in ("abs", "log", "inv"):
+            np.testing.assert_allclose(ev.depth_scale_factor(pred[m], gt[m], s_), gold["scale"][ci][s_], rtol=2e-4)
+    mc = mk.motion_cases()
+    it = iter(gold["motion"])
+    for i in range(len(mc)):
+        for norm in (True, False):
+            a, b = mc[i], mc[(i + 1) % len(mc)]
+            want = next(it)
+            got = ev.motion_errors(a[0:3], a[3:6], b[0:3], b[3:6], normalize_translations=norm)
+            np.testing.assert_allclose([got["rotation_deg"], got["translation_distance"], got["translation_angle_deg"]], want,
+                                       rtol=1e-6, atol=1e-6)
+    fa, fb = mk.flow_cases()
+    np.testing.assert_allclose(ev.flow_epe(fa, fb), gold["flow_epe"], rtol=1e-5)
+
+
 @pytest.mark.gpu
 def test_four_stage_protocol(gpu_ctx):
     import sys, os
