@@ -9,12 +9,18 @@
  * absent from /root/reference -- tensorflow 1.4.0 (Dockerfile:14; conv2d / conv2d_transpose /
  * dense) and lmbspecialops at an unknown commit (.gitmodules:1-3, empty submodule; depth_to_flow,
  * flow_to_depth, warp2d, leaky_relu, ...).  The reference ships no tests or golden vectors for
- * this path.  What IS pinned: the depth->flow geometry (pixel centre x+0.5,
- * X2 = R*X1 + t, project with K) against the reference's own in-tree implementation
- * dataset_tools/view_tools_cython.pyx:9-59, compiled and run here by oracle/build_ref.py and
- * stored in tests/golden/sculpture_geometry.npz; and the angle-axis convention of
- * python/depthmotionnet/helpers.py:37-57.  Everything else restates published semantics at the
- * reference's call sites, which each function cites.
+ * this path.  What IS pinned, against the reference's own in-tree code compiled
+ * and run here by oracle/build_ref.py with the answers stored in tests/golden/sculpture_geometry.npz:
+ *   - depth_to_flow: its OUTPUT (flow in pixels, NaN at invalid depth) equals the reference's
+ *     flow-from-depth routine dataset_tools/view_tools_cython.pyx:196-244 on the sculpture pair, and its
+ *     geometry (pixel centre x+0.5, X2 = R*X1 + t, project with K) the visibility / depth-ratio
+ *     routines :9-59, :108-161;
+ *   - flow_to_depth (both methods): applied to that reference flow they return the reference's depth;
+ *   - the angle-axis convention of python/depthmotionnet/helpers.py:37-57.
+ * Still unpinned: warp2d's border / rounding rules, scale_invariant_gradient, median3x3_downsample,
+ * and every TensorFlow layer (conv2d 'valid' on a padded input, conv2d_transpose, dense, 'same'
+ * padding of the v2 model): they restate published semantics at the reference's call sites, which each
+ * function cites.
  *
  * All tensors are NCHW float32, contiguous.
  */

@@ -33,6 +33,38 @@ def test_depth_to_flow(gpu_ctx, shape, inverse, normalize, gate):
     assert rel_l1(got[m], want[m]) < 1e-4
 
 
+def _golden_sculpture():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sculpture_geometry.npz"))
+    R = g["Rt2"][:, :3].astype(np.float64)
+    angle = np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
+    axis = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (2 * np.sin(angle))
+    return g, (axis * angle).astype(np.float32)[None], g["Rt2"][:, 3].astype(np.float32)[None]
+
+
+def test_depth_to_flow_matches_reference_golden(gpu_ctx):
+    """HIP depth_to_flow == the flow the reference's own routine (view_tools_cython.pyx:196-244) computes for the sculpture
+    pair (tests/golden/make_golden.py ran it in the build container): pixels, NaN at invalid depth"""
+    g, aa, t = _golden_sculpture()
+    depth1, want = g["depth1"], g["flow12"]
+    got = gpu_ctx.depth_to_flow(depth1[None, None], K_DEMON, aa, t, False, False, False)[0]
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    m = np.isfinite(want)
+    assert np.abs(got[m] - want[m]).max() < 2e-3 and rel_l1(got[m], want[m]) < 1e-5
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_flow_to_depth_recovers_reference_depth(gpu_ctx, method):
+    """flow_to_depth (DLT / SVD) and flow_to_depth2 (closed form) applied to the REFERENCE's flow with the sculpture motion
+    give back the reference's depth map (depth, not inverse; flow in pixels)"""
+    g, aa, t = _golden_sculpture()
+    depth1, flow = g["depth1"], g["flow12"]
+    m = np.isfinite(flow).all(0)
+    f = np.where(m, flow, 0.0).astype(np.float32)
+    got = gpu_ctx.flow_to_depth(f[None], K_DEMON, aa, t, False, False, method)[0, 0]
+    assert rel_l1(got[m], depth1[m]) < 1e-4
+
+
 @pytest.mark.parametrize("method", [0, 1])
 @pytest.mark.parametrize("shape", [(1, 48, 64), (3, 48, 64), (2, 120, 160)])
 def test_flow_to_depth(gpu_ctx, method, shape):

@@ -65,6 +65,40 @@ def test_golden_visible_mask_and_depth_ratio():
     assert close.mean() > 0.995
 
 
+def test_golden_flow_from_reference_routine():
+    """depth_to_flow of the oracle == the reference's own flow-from-depth routine (view_tools_cython.pyx:196-244, run in the
+    build container by tests/golden/make_golden.py) on the sculpture pair: flow in pixels, NaN at invalid depth."""
+    g = np.load(GOLDEN)
+    depth1, want = g["depth1"], g["flow12"]
+    aa = _aa_from_R(g["Rt2"][:, :3])[None]
+    t = g["Rt2"][:, 3].astype(np.float32)[None]
+    flow = ops_ref.depth_to_flow(depth1[None, None], K_DEMON, aa, t, inverse_depth=False, normalize_flow=False)[0]
+    assert np.array_equal(np.isfinite(flow), np.isfinite(want))
+    m = np.isfinite(want)
+    assert m.mean() > 0.9
+    assert np.abs(flow[m] - want[m]).max() < 2e-3          # pixels; flows reach ~80 px, float32 on both sides
+    assert rel_l1(flow[m], want[m]) < 1e-5
+    # normalised flow and inverse depth are the same numbers divided by W / H (blocks_original.py:155-162 arguments)
+    with np.errstate(divide="ignore"):
+        inv = 1.0 / depth1[None, None]
+    fn = ops_ref.depth_to_flow(inv, K_DEMON, aa, t, inverse_depth=True, normalize_flow=True)[0]
+    H, W = depth1.shape
+    assert rel_l1(fn[0][m[0]] * W, want[0][m[0]]) < 1e-5 and rel_l1(fn[1][m[1]] * H, want[1][m[1]]) < 1e-5
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_golden_flow_to_depth_recovers_reference_depth(method):
+    """flow_to_depth / flow_to_depth2 of the oracle applied to the reference's flow give back the reference's depth map"""
+    g = np.load(GOLDEN)
+    depth1, flow = g["depth1"], g["flow12"]
+    aa = _aa_from_R(g["Rt2"][:, :3])[None]
+    t = g["Rt2"][:, 3].astype(np.float32)[None]
+    m = np.isfinite(flow).all(0)
+    f = np.where(m, flow, 0.0).astype(np.float32)
+    d = ops_ref.flow_to_depth(f[None], K_DEMON, aa, t, inverse_depth=False, normalized_flow=False, method=method)[0, 0]
+    assert rel_l1(d[m], depth1[m]) < 1e-5
+
+
 def test_depth_to_flow_known_answers():
     H, W = 6, 8
     d = np.full((1, 1, H, W), 2.0, np.float32)
