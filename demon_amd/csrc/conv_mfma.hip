@@ -48,8 +48,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     const int tid = threadIdx.x;
     const int cls = blockIdx.z / a.ksplit;  // output parity class (transposed conv) ...
     const int zs = blockIdx.z - cls * a.ksplit;  // ... and K slice (split-K for the small feature maps)
-    const int m0 = blockIdx.y * BM;
-    const long p0 = (long)blockIdx.x * BN;
+    unsigned bx, by;
+    xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    const int m0 = by * BM;
+    const long p0 = (long)bx * BN;
     const long P = (long)a.N * a.Hp * a.Wp;
     const float *__restrict__ wp = a.wp + (long)cls * a.cls_w_stride;
     const KEntry *__restrict__ ktab = a.ktab + (long)cls * a.Kpad;

@@ -40,10 +40,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     const int tid = threadIdx.x;
     const int cls = blockIdx.z / a.ksplit;
     const int zs = blockIdx.z - cls * a.ksplit;
-    const int m0 = blockIdx.y * BM;
+    unsigned bx, by;
+    xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    const int m0 = by * BM;
     // tile -> (image group, tile row, tile col)
-    const int tyg = fdiv(blockIdx.x, a.m_tilesx);
-    const int tx = blockIdx.x - tyg * a.tiles_x;
+    const int tyg = fdiv((int)bx, a.m_tilesx);
+    const int tx = (int)bx - tyg * a.tiles_x;
     const int tgrp = fdiv(tyg, a.m_tilesy);
     const int ty = tyg - tgrp * a.tiles_y;
     const int n0 = tgrp * a.G;

@@ -253,6 +253,8 @@ void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
     a.act = L->act;
     a.cls_w_stride = (long)L->Krows * L->Mpad;
     a.ksplit = 1;
+    static const int xcd_order = getenv("DEMON_XCD_ORDER") ? atoi(getenv("DEMON_XCD_ORDER")) : 1;
+    a.xcd = xcd_order;
     if (L->kind == Layer::DECONV) {
         a.Hp = L->in.H; a.Wp = L->in.W; a.sy = 1; a.sx = 1; a.osy = 2; a.osx = 2;
     } else {
@@ -321,7 +323,7 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
     a.Hp = Hp; a.Wp = Wp; a.sh = sh; a.sw = sw;
     a.Cout = L->Cout; a.Mpad = L->Mpad; a.cls_w_stride = ca.cls_w_stride;
     a.Ho = ca.Ho; a.Wo = ca.Wo; a.out_n_stride = ca.out_n_stride; a.osy = ca.osy; a.osx = ca.osx;
-    a.act = L->act; a.nsteps_total = chunks;
+    a.act = L->act; a.nsteps_total = chunks; a.xcd = ca.xcd;
     for (int cls = 0; cls < 4; ++cls) {
         if (L->kind == Layer::DECONV) {
             static const int tap_d[2][2] = {{0, -1}, {1, 0}};

@@ -28,6 +28,21 @@ struct View {
 
 // One entry of the implicit-GEMM K table: where the B operand element of reduction index k comes
 // from, relative to the output pixel's anchor (y*sy, x*sx) in the input plane.
+// XCD-aware tile order.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with its own L2.  All
+// workgroups of a launch's x-y plane whose linear id is congruent mod 8 therefore share an L2; this maps them onto a CONTIGUOUS run
+// of the logical tile order (Cout tile fastest, then pixel tile), so the Cout tiles of one pixel tile and neighbouring pixel tiles
+// (which share input halos) hit the same L2 instead of fetching the input from HBM once per XCD.  A bijection of the plane for any
+// grid size, i.e. correct whatever the real dispatch order is.
+__device__ __forceinline__ void xcd_tile(int mode, unsigned bx_in, unsigned by_in, unsigned gx, unsigned gy, unsigned &bx, unsigned &by)
+{
+    if (!mode) { bx = bx_in; by = by_in; return; }
+    const unsigned T = gx * gy, L = bx_in + gx * by_in;
+    const unsigned c = L & 7u, slot = L >> 3;
+    const unsigned q = c * (T >> 3) + (c < (T & 7u) ? c : (T & 7u)) + slot;
+    bx = q / gy;
+    by = q - bx * gy;
+}
+
 struct KEntry {
     int delta;  // ci*H*W + dy*W + dx   (elements)
     int dydx;   // (dy << 16) | (dx & 0xffff);  dy = -30000 marks padding rows (k >= K)
@@ -58,6 +73,7 @@ struct ConvArgs {
     float *ws;          // split-K workspace [cls][slice][Mpad][P]
     int ksplit;         // number of K slices (1 = fused epilogue)
     int dbg;            // ablation switches for tuning experiments (0 in production)
+    int xcd;            // 1: XCD-aware tile order (xcd_tile)
     long out_plane;     // elements between output channel planes (Ho*Wo unless the buffer is padded)
 };
 
@@ -94,6 +110,7 @@ struct PatchArgs {
     long out_n_stride;
     int osy, osx;
     int act, ksplit, nsteps_total;
+    int xcd;             // 1: XCD-aware tile order (xcd_tile)
     // magic numbers for exact unsigned division of the small prologue indices: n / d == mulhi(n, ceil(2^32 / d)) for n < 2^20, d < 2^12
     unsigned m_plane, m_pw, m_thtw, m_tw, m_tilesx, m_tilesy;
 };
