@@ -22,15 +22,22 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // n / d for the small indices of the prologue / epilogue (n < 2^20, d < 2^12) with the host-provided magic ceil(2^32 / d)
 __device__ __forceinline__ int fdiv(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }  // magic 0 <=> d == 1
 
+// BM == 16 (Cout <= 16 heads): v_mfma_f32_16x16x4_f32 -- a wave owns 16 channels x TN*16 pixels and one MFMA eats 4 reduction
+// indices (lane: row / pixel = lane & 15, k = lane >> 4); same FLOP rate as the 32x32x2 tile without multiplying 16 rows of zeros.
 template <int BM, int WM, int WN, int TM, int TN, int NTAPS, int CKS, int EPT>
 __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 {
+    constexpr bool M16 = BM == 16;
     constexpr int NT = 64 * WM * WN;
     constexpr int KD = NTAPS * CKS;  // reduction depth of one K-step
-    constexpr int NG = KD / 2;       // MFMA groups (k pairs) per step
+    constexpr int KG = M16 ? 4 : 2;  // reduction indices per MFMA
+    constexpr int NG = KD / KG;      // MFMA groups per step
+    constexpr int PXW = M16 ? 16 : 32;  // pixels per MFMA column block
+    constexpr int NR = M16 ? 4 : 16;    // accumulator registers per MFMA
     constexpr int A4 = KD * BM / 4;  // float4 chunks of the A tile
     constexpr int APER = (A4 + NT - 1) / NT;
-    static_assert(BM == WM * TM * 32 && CKS % 2 == 0, "bad tile");
+    static_assert((M16 ? (WM == 1 && TM == 1) : BM == WM * TM * 32) && CKS % KG == 0, "bad tile");
+    using AccT = typename std::conditional<M16, floatx4, floatx16>::type;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                           // [2][KD][BM]
@@ -89,30 +96,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, lhi = lane >> 5;
+    const int l31 = M16 ? (lane & 15) : (lane & 31), lhi = M16 ? (lane >> 4) : (lane >> 5);  // row / pixel inside the MFMA block, k inside the group
 
     // ---- B fragment addressing: byte offset of this lane's pixel inside a patch buffer (+ odd-k plane)
     const int tile_pixels = a.G * a.TH * a.TW;
     int bbase[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        int pj = (wn * TN + j) * 32 + l31;
+        int pj = (wn * TN + j) * PXW + l31;
         if (pj >= tile_pixels) pj = 0;  // padding lanes read a valid address; masked at the store
         const int g = fdiv(pj, a.m_thtw), rem = pj - g * (a.TH * a.TW);
         const int py = fdiv(rem, a.m_tw), px = rem - py * a.TW;
         bbase[j] = 4 * (g * CKS * a.PS + py * a.sh * a.PW + px * a.sw + lhi * a.PS);
     }
-    int so[NG];  // per k-pair: (even channel of the pair)*PS + tap offset, bytes (wave uniform)
+    int so[NG];  // per k group: (first channel of the group)*PS + tap offset, bytes (wave uniform)
 #pragma unroll
-    for (int kk = 0; kk < NG; ++kk) so[kk] = 4 * (((2 * kk) % CKS) * a.PS + a.tapoff[cls][(2 * kk) / CKS]);
+    for (int kk = 0; kk < NG; ++kk) so[kk] = 4 * (((KG * kk) % CKS) * a.PS + a.tapoff[cls][(KG * kk) / CKS]);
 
-    floatx16 acc[TM][TN];
+    AccT acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.0f;
 
     // two register sets: the global loads run TWO K-steps ahead of the MFMAs (the data of step s+1 is written
     // to LDS at the end of step s from the set that was loaded during step s-1), so a load has a full K-step
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
         float av[NG][TM], bv[NG][TN];
 #pragma unroll
         for (int kk = 0; kk < NG; ++kk) {
-            const int k = 2 * kk + lhi;
+            const int k = KG * kk + lhi;
 #pragma unroll
             for (int i = 0; i < TM; ++i) av[kk][i] = A[k * BM + (wm * TM + i) * 32 + l31];
 #pragma unroll
@@ -158,8 +165,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
+                }
             if (PREFETCH) {
                 constexpr int GH = NG / 2 > 0 ? NG / 2 : 1;  // loads behind the first half of the groups
                 if (g < GH) {
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
         const int q = l31 >> 2, li = lane & 3;  // quad index inside the half wave, lane inside the quad
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int pj = (wn * TN + j) * 32 + 4 * q;  // first of this lane's 4 pixels
+            const int pj = (wn * TN + j) * PXW + 4 * q;  // first of this lane's 4 pixels
             const bool pv = pj < tile_pixels;
             const int pjc = pv ? pj : 0;
             const int g = fdiv(pjc, a.m_thtw), rem = pjc - g * (a.TH * a.TW);
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
+                for (int rb = 0; rb < NR / 4; ++rb) {
                     float v0 = acc[i][j][4 * rb + 0], v1 = acc[i][j][4 * rb + 1], v2 = acc[i][j][4 * rb + 2], v3 = acc[i][j][4 * rb + 3];
                     // stage 1: exchange with the lane at distance 1 (quad_perm [1,0,3,2])
                     {
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int pj = (wn * TN + j) * 32 + l31;
+        const int pj = (wn * TN + j) * PXW + l31;
         if (pj >= tile_pixels) continue;
         const int g = fdiv(pj, a.m_thtw), rem = pj - g * (a.TH * a.TW);
         const int py = fdiv(rem, a.m_tw), px = rem - py * a.TW;
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     const int co = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     ws[(long)co * Ptot] = acc[i][j][r];
                 }
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     const int co = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                     if (co < a.Cout) {
                         float v = acc[i][j][r] + a.bias[co];
@@ -312,10 +321,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
 
 // ---- host side --------------------------------------------------------------------------------------
 struct PatchTile { int bm, bn, threads; };
-static const PatchTile kPatchTiles[PTILE_COUNT] = {{128, 128, 256}, {64, 128, 256}, {32, 128, 256}, {64, 64, 256}, {128, 64, 256}, {32, 64, 128}};
+static const PatchTile kPatchTiles[PTILE_COUNT] = {{128, 128, 256}, {64, 128, 256}, {32, 128, 256}, {64, 64, 256}, {128, 64, 256}, {32, 64, 128}, {16, 128, 256}};
 
-int patch_cks(int ntaps)
+int patch_cks(int ntaps, int tile)
 {
+    if (kPatchTiles[tile].bm == 16) return ntaps == 9 ? 4 : 0;  // 16-row MFMA tile: 3x3 heads only (K groups of 4 channels)
     switch (ntaps) {
         case 3: return 8;
         case 4: return 4;
@@ -329,10 +339,11 @@ int patch_cks(int ntaps)
 int patch_tile_bm(int tile) { return kPatchTiles[tile].bm; }
 int patch_tile_bn(int tile) { return kPatchTiles[tile].bn; }
 int patch_tile_threads(int tile) { return kPatchTiles[tile].threads; }
+int patch_tile_mtiles(int tile, int Cout, int Mpad) { return kPatchTiles[tile].bm == 16 ? (Cout + 15) / 16 : Mpad / kPatchTiles[tile].bm; }
 
 size_t patch_lds_bytes(int tile, int ntaps, int G, int PS)
 {
-    const int cks = patch_cks(ntaps);
+    const int cks = patch_cks(ntaps, tile);
     return sizeof(float) * (2ul * ntaps * cks * kPatchTiles[tile].bm + 2ul * G * cks * PS);
 }
 
@@ -350,10 +361,16 @@ static void launch_patch_taps(const PatchArgs &a, int ntaps, dim3 grid, size_t l
     }
 }
 
-template <int BM, int WM, int WN, int TM, int TN>
-static void launch_patch_ept(const PatchArgs &a, int ntaps, dim3 grid, size_t lds, hipStream_t s)
+template <int EPT>
+static void launch_patch16(const PatchArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    const long elems = (long)a.G * patch_cks(ntaps) * a.PH * a.PW;
+    hipLaunchKernelGGL((conv_patch_kernel<16, 1, 4, 1, 2, 9, 4, EPT>), grid, dim3(256), lds, s, a);
+}
+
+template <int BM, int WM, int WN, int TM, int TN>
+static void launch_patch_ept(const PatchArgs &a, int ntaps, int cks, dim3 grid, size_t lds, hipStream_t s)
+{
+    const long elems = (long)a.G * cks * a.PH * a.PW;
     const int per_thread = (int)((elems + 64 * WM * WN - 1) / (64 * WM * WN));
     if (per_thread <= 2) launch_patch_taps<BM, WM, WN, TM, TN, 2>(a, ntaps, grid, lds, s);
     else if (per_thread <= 4) launch_patch_taps<BM, WM, WN, TM, TN, 4>(a, ntaps, grid, lds, s);
@@ -364,15 +381,24 @@ void launch_conv_patch(const PatchArgs &a, int tile, int ntaps, int nclasses, hi
 {
     const PatchTile ti = kPatchTiles[tile];
     const int groups = (a.N + a.G - 1) / a.G;
-    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / ti.bm), (unsigned)(nclasses * a.ksplit));
+    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)patch_tile_mtiles(tile, a.Cout, a.Mpad), (unsigned)(nclasses * a.ksplit));
     const size_t lds = patch_lds_bytes(tile, ntaps, a.G, a.PS);
+    const int cks = patch_cks(ntaps, tile);
     switch (tile) {
-        case PTILE_128x128: launch_patch_ept<128, 2, 2, 2, 2>(a, ntaps, grid, lds, stream); break;
-        case PTILE_64x128:  launch_patch_ept<64, 2, 2, 1, 2>(a, ntaps, grid, lds, stream); break;
-        case PTILE_32x128:  launch_patch_ept<32, 1, 4, 1, 1>(a, ntaps, grid, lds, stream); break;
-        case PTILE_128x64:  launch_patch_ept<128, 2, 2, 2, 1>(a, ntaps, grid, lds, stream); break;
-        case PTILE_32x64:   launch_patch_ept<32, 1, 2, 1, 1>(a, ntaps, grid, lds, stream); break;
-        default:            launch_patch_ept<64, 2, 2, 1, 1>(a, ntaps, grid, lds, stream); break;
+        case PTILE_128x128: launch_patch_ept<128, 2, 2, 2, 2>(a, ntaps, cks, grid, lds, stream); break;
+        case PTILE_64x128:  launch_patch_ept<64, 2, 2, 1, 2>(a, ntaps, cks, grid, lds, stream); break;
+        case PTILE_32x128:  launch_patch_ept<32, 1, 4, 1, 1>(a, ntaps, cks, grid, lds, stream); break;
+        case PTILE_128x64:  launch_patch_ept<128, 2, 2, 2, 1>(a, ntaps, cks, grid, lds, stream); break;
+        case PTILE_32x64:   launch_patch_ept<32, 1, 2, 1, 1>(a, ntaps, cks, grid, lds, stream); break;
+        case PTILE_16x128: {
+            const long elems = (long)a.G * cks * a.PH * a.PW;
+            const int per_thread = (int)((elems + 255) / 256);
+            if (per_thread <= 2) launch_patch16<2>(a, grid, lds, stream);
+            else if (per_thread <= 4) launch_patch16<4>(a, grid, lds, stream);
+            else launch_patch16<PATCH_EPT>(a, grid, lds, stream);
+            break;
+        }
+        default:            launch_patch_ept<64, 2, 2, 1, 1>(a, ntaps, cks, grid, lds, stream); break;
     }
 }
 

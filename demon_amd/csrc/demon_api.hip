@@ -272,11 +272,8 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
     pp.ok = false;
     if (!enabled || L->kind == Layer::DENSE) return false;
     const int ntaps = L->kind == Layer::DECONV ? 4 : L->kh * L->kw;
-    const int cks = patch_cks(ntaps);
-    if (!cks) return false;
     if (L->kind == Layer::CONV && L->kh > 1 && L->kw > 1 && !(L->kh == 3 && L->kw == 3)) return false;
-    const int chunks = (L->Cin + cks - 1) / cks;
-    if ((float)L->Cin / (chunks * cks) < 0.7f) return false;  // too much zero padding in K: the im2col kernel is better
+    int chunks = 0;
     ConvArgs ca;
     fill_conv_args(L, n, ws, ca);
     const int Hp = ca.Hp, Wp = ca.Wp, sh = ca.sy, sw = ca.sx;
@@ -287,6 +284,14 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
         if (only_tile >= 0 && tile != only_tile) continue;
         const int bm = patch_tile_bm(tile), bn = patch_tile_bn(tile), nt = patch_tile_threads(tile);
         if (L->Mpad % bm) continue;
+        // the 16-row MFMA tile is for Cout <= 16 heads, and there it replaces the 32-row tiles (half of their MFMA rows are zeros)
+        const bool m16_ok = L->Cout <= 16 && patch_cks(ntaps, PTILE_16x128) != 0;
+        if (only_tile < 0 && (bm == 16) != m16_ok) continue;
+        if (bm == 16 && L->Cout > 16) continue;
+        const int tcks = patch_cks(ntaps, tile);
+        if (!tcks) continue;
+        const int tchunks = (L->Cin + tcks - 1) / tcks;
+        if ((float)L->Cin / (tchunks * tcks) < 0.7f) continue;  // too much zero padding in K: the im2col kernel is better
         for (int tw_sel = 0; tw_sel < 4; ++tw_sel) {
             int TW = tw_sel == 0 ? (Wp < bn ? Wp : bn) : (bn >> tw_sel);  // Wp/bn, bn/2, bn/4, bn/8
             if (TW < 8 || TW > Wp || TW > bn) continue;
@@ -295,20 +300,21 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
             int G = 1;
             if (TH == Hp && TW == Wp) { G = bn / (TH * TW); if (G < 1) G = 1; if (G > n) G = n; }
             const int PH = (TH - 1) * sh + ext_y, PW = (TW - 1) * sw + ext_x, PS = PH * PW;
-            const long elems = (long)G * cks * PS;
+            const long elems = (long)G * tcks * PS;
             if ((elems + nt - 1) / nt > PATCH_EPT) continue;
             if (patch_lds_bytes(tile, ntaps, G, PS) > 64 * 1024) continue;
             const int tiles_y = (Hp + TH - 1) / TH, tiles_x = (Wp + TW - 1) / TW, groups = (n + G - 1) / G;
             const double useful = (double)n * Hp * Wp;
             const double tiles = (double)groups * tiles_y * tiles_x;
             const double mfma_waste = tiles * bn / useful;          // >= 1: padded MFMA columns
-            const double staged = tiles * elems / useful / cks;     // staged input floats per output pixel per channel
+            const double staged = tiles * elems / useful / tcks;    // staged input floats per output pixel per channel
             // cost model: MFMA time dominates; staging adds ~ (staged / ntaps) relative to one MFMA column, and small Cout
             // tiles pay more for it; calibrated loosely on layer sweeps
             const float cost = (float)(mfma_waste * (1.0 + 0.35 * staged / ntaps * (128.0 / bm)) * (bm == 128 ? 1.0 : (bm == 64 ? 1.04 : 1.10)));
             if (cost < best_cost) {
                 best_cost = cost;
                 pp.tile = tile;
+                chunks = tchunks;
                 PatchArgs &a = pp.a;
                 a.G = G; a.TH = TH; a.TW = TW; a.tiles_y = tiles_y; a.tiles_x = tiles_x; a.PH = PH; a.PW = PW; a.PS = PS;
                 pp.ok = true;
@@ -342,7 +348,7 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
     }
     // split-K over channel chunks when the grid is too small to fill the chip
     const long groups = (n + a.G - 1) / a.G;
-    const long wgs = groups * a.tiles_y * a.tiles_x * (L->Mpad / patch_tile_bm(pp.tile)) * L->ncls;
+    const long wgs = groups * a.tiles_y * a.tiles_x * patch_tile_mtiles(pp.tile, L->Cout, L->Mpad) * L->ncls;
     int split = 1;
     if (wgs < 384) {
         split = (int)((512 + wgs - 1) / wgs);
@@ -472,7 +478,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
         if (!plan_patch(L, n, c->d_ws, pp, t)) continue;
         cands.push_back({1, t, 0});  // 0 = the planner's own split-K
         const long groups = (n + pp.a.G - 1) / pp.a.G;
-        const long wgs = groups * pp.a.tiles_y * pp.a.tiles_x * (L->Mpad / patch_tile_bm(t)) * L->ncls;
+        const long wgs = groups * pp.a.tiles_y * pp.a.tiles_x * patch_tile_mtiles(t, L->Cout, L->Mpad) * L->ncls;
         for (int ks : {1, 2, 3, 4, 6, 8}) {
             if (ks == pp.a.ksplit || ks > pp.a.nsteps_total / 2 || wgs * ks > 2048) continue;
             if (ks > 1 && (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats) continue;

@@ -17,6 +17,7 @@ LAYERS = [
     ("conv", 64, 64, 3, 3, 1, 1, 24, 32), ("conv", 32, 64, 3, 3, 2, 2, 24, 32), ("conv", 512, 24, 3, 3, 1, 1, 6, 8),
     ("conv", 6, 32, 9, 1, 2, 1, 48, 64), ("conv", 24, 4, 3, 3, 1, 1, 6, 8), ("conv", 24, 4, 3, 3, 1, 1, 48, 64),
     ("conv", 16, 1, 3, 3, 1, 1, 40, 136), ("conv", 5, 3, 3, 3, 1, 1, 9, 7), ("conv", 24, 2, 3, 3, 1, 1, 17, 130),
+    ("conv", 64, 16, 3, 3, 1, 1, 48, 64), ("conv", 64, 16, 3, 3, 1, 1, 21, 37), ("conv", 30, 12, 3, 3, 2, 2, 24, 32),
     ("deconv", 512, 256, 0, 0, 0, 0, 6, 8), ("deconv", 514, 128, 0, 0, 0, 0, 12, 16), ("deconv", 128, 32, 0, 0, 0, 0, 24, 32),
 ]
 
@@ -45,7 +46,7 @@ def test_all_variants_agree(gpu_ctx, layer):
         w = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
     b = rng.standard_normal((cout,)).astype(np.float32)
     want = _ref(kind, x, w, b, (sh, sw))
-    plans = [(3, 0, 0)] + [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(6) for ks in (0, 2, 3, 5)]
+    plans = [(3, 0, 0)] + [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(7) for ks in (0, 2, 3, 5)]
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
