@@ -196,13 +196,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
         for (int i = 0; i < EPT; ++i) load_patch_one(pregA, i, pbase);
 #pragma unroll
         for (int i = 0; i < APER; ++i) load_a_one(aregA, i, abase);
-        const int s1 = phys(1);
-        const float *__restrict__ pbase1 = in0 + (long)s1 * CKS * a.H * a.W;
-        const float *__restrict__ abase1 = wp + (long)s1 * CKS * a.Mpad;
+        if (nsteps > 1) {  // a one-step slice has nothing to run ahead to
+            const int s1 = phys(1);
+            const float *__restrict__ pbase1 = in0 + (long)s1 * CKS * a.H * a.W;
+            const float *__restrict__ abase1 = wp + (long)s1 * CKS * a.Mpad;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) load_patch_one(pregB, i, pbase1);
+            for (int i = 0; i < EPT; ++i) load_patch_one(pregB, i, pbase1);
 #pragma unroll
-        for (int i = 0; i < APER; ++i) load_a_one(aregB, i, abase1);
+            for (int i = 0; i < APER; ++i) load_a_one(aregB, i, abase1);
+        }
         store_tiles(pregA, aregA, 0, okmask_of(p0s));
     }
     __syncthreads();

@@ -17,6 +17,7 @@ LAYERS = [
     ("conv", 64, 64, 3, 3, 1, 1, 24, 32), ("conv", 32, 64, 3, 3, 2, 2, 24, 32), ("conv", 512, 24, 3, 3, 1, 1, 6, 8),
     ("conv", 6, 32, 9, 1, 2, 1, 48, 64), ("conv", 24, 4, 3, 3, 1, 1, 6, 8), ("conv", 24, 4, 3, 3, 1, 1, 48, 64),
     ("conv", 16, 1, 3, 3, 1, 1, 40, 136), ("conv", 5, 3, 3, 3, 1, 1, 9, 7), ("conv", 24, 2, 3, 3, 1, 1, 17, 130),
+    ("conv", 4, 32, 3, 3, 1, 1, 40, 72), ("conv", 5, 32, 9, 1, 2, 1, 48, 64), ("conv", 3, 20, 3, 3, 1, 1, 17, 33), ("conv", 6, 32, 1, 9, 1, 2, 24, 128),
     ("conv", 64, 16, 3, 3, 1, 1, 48, 64), ("conv", 64, 16, 3, 3, 1, 1, 21, 37), ("conv", 30, 12, 3, 3, 2, 2, 24, 32),
     ("deconv", 512, 256, 0, 0, 0, 0, 6, 8), ("deconv", 514, 128, 0, 0, 0, 0, 12, 16), ("deconv", 128, 32, 0, 0, 0, 0, 24, 32),
 ]
