@@ -381,7 +381,6 @@ static void launch_patch_ept(const PatchArgs &a, int ntaps, int cks, dim3 grid, 
 
 void launch_conv_patch(const PatchArgs &a, int tile, int ntaps, int nclasses, hipStream_t stream)
 {
-    const PatchTile ti = kPatchTiles[tile];
     const int groups = (a.N + a.G - 1) / a.G;
     dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)patch_tile_mtiles(tile, a.Cout, a.Mpad), (unsigned)(nclasses * a.ksplit));
     const size_t lds = patch_lds_bytes(tile, ntaps, a.G, a.PS);
