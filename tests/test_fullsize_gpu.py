@@ -1,0 +1,98 @@
+"""Parity at BASELINE.json's FULL sizes -- configs[2] (batch 32 @256x192, the metric's configuration, with the shipped launch
+plan) and configs[4] (batch 64 @640x480) -- where the CPU oracle cannot run the whole batch in test time.  Checked through
+size-independent properties of the path, plus the oracle on a sample of the batch:
+
+  * pairs are independent (no batch statistics anywhere): row i of the big batch == the same pair evaluated alone /
+    in a small batch on another context (other launch plans -> summation order only);
+  * permutation equivariance: permuting the pairs permutes the outputs, bit for bit;
+  * determinism: two runs are bit-identical;
+  * the oracle agrees on sampled pairs of the big batch (relative L1 <= 1e-3);
+  * depth -> flow -> depth round trip through the two geometry kernels at full batch and resolution.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_l1, make_inputs
+from oracle import net_ref
+
+pytestmark = pytest.mark.gpu
+KEYS = ("predict_flow5", "predict_flow2", "predict_depth2", "predict_normal2", "predict_rotation", "predict_translation",
+        "predict_depth0")
+
+
+def test_config2_batch32_full_pipeline(gpu_ctx, synth_weights):
+    from demon_amd import DemonContext
+    n = 32
+    ctx = DemonContext(0, n, 192, 256)
+    try:
+        ctx.set_weights(synth_weights)
+        assert ctx.load_tuned_plan(n), "the shipped plan for the metric's configuration must load"
+        pair, img2_2 = make_inputs(n, seed=40)
+        got = ctx.full(pair, img2_2, iterations=3)
+        assert all(np.isfinite(got[k]).all() for k in KEYS)
+        # determinism
+        again = ctx.full(pair, img2_2, iterations=3)
+        for k in KEYS:
+            np.testing.assert_array_equal(got[k], again[k])
+        # permutation equivariance (bit exact: same kernels, same per-pair arithmetic)
+        perm = np.random.default_rng(41).permutation(n)
+        pgot = ctx.full(pair[perm], img2_2[perm], iterations=3)
+        for k in KEYS:
+            np.testing.assert_array_equal(pgot[k], got[k][perm])
+        # independence: pairs 0..3 of the batch == the same pairs on the small-batch context (heuristic plans)
+        small = gpu_ctx.full(pair[:4], img2_2[:4], iterations=3)
+        for k in KEYS:
+            assert rel_l1(got[k][:4], small[k]) < 1e-4, k
+        # the oracle on two pairs of the batch
+        sel = [5, 31]
+        want = net_ref.DemonRef(synth_weights).full(pair[sel], img2_2[sel], iterations=3)
+        for k in KEYS:
+            err = rel_l1(got[k][sel], want[k])
+            assert err < 1e-3, "%s rel L1 %.3e" % (k, err)
+    finally:
+        ctx.close()
+
+
+def test_config4_batch64_640x480(synth_weights):
+    from demon_amd import DemonContext, weights
+    H, W, n = 480, 640, 64
+    w = weights.synthetic_weights(seed=1, height=H, width=W)
+    big = DemonContext(0, n, H, W)
+    one = DemonContext(0, 1, H, W)
+    try:
+        big.set_weights(w)
+        one.set_weights(w)
+        big.load_tuned_plan(n)
+        pair, img2_2 = make_inputs(n, H, W, seed=42)
+        got = big.full(pair, img2_2, iterations=3)
+        assert all(np.isfinite(got[k]).all() for k in KEYS)
+        again = big.full(pair, img2_2, iterations=3)
+        for k in KEYS:
+            np.testing.assert_array_equal(got[k], again[k])
+        # independence: pair 17 alone on a batch-1 context
+        single = one.full(pair[17:18], img2_2[17:18], iterations=3)
+        for k in KEYS:
+            assert rel_l1(got[k][17:18], single[k]) < 1e-4, k
+        # the oracle on one pair (one iteration less would not exercise less code; 3 iterations take ~20 s of CPU)
+        want = net_ref.DemonRef(w).full(pair[63:64], img2_2[63:64], iterations=3)
+        for k in KEYS:
+            err = rel_l1(got[k][63:64], want[k])
+            assert err < 1e-3, "%s rel L1 %.3e" % (k, err)
+        # geometry kernels at the full level-2 size of this config: inverse depth -> flow -> inverse depth
+        rng = np.random.default_rng(43)
+        h2, w2 = H // 4, W // 4
+        inv_depth = (0.2 + rng.random((n, 1, h2, w2))).astype(np.float32)
+        rot = (0.05 * rng.standard_normal((n, 3))).astype(np.float32)
+        tr = rng.standard_normal((n, 3)).astype(np.float32)
+        tr /= np.linalg.norm(tr, axis=1, keepdims=True)
+        K = np.array([0.89115971, 1.18821287, 0.5, 0.5], np.float32)
+        flow = big.depth_to_flow(inv_depth, K, rot, tr, True, True, False)
+        for method in (0, 1):
+            back = big.flow_to_depth(flow, K, rot, tr, True, True, method)
+            # pixels near the epipole are ill-conditioned in any triangulation: judge in aggregate and by the median
+            m = np.isfinite(back) & np.isfinite(flow[:, :1])
+            assert m.mean() > 0.99
+            assert np.median(np.abs(back[m] - inv_depth[m]) / inv_depth[m]) < 1e-4
+    finally:
+        big.close()
+        one.close()
