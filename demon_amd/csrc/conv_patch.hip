@@ -321,12 +321,234 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// deconv4_kernel: all FOUR sub-pixel classes of a 4x4 stride-2 transposed conv in one workgroup (blocks_original.py:64-75, :97-110).
+//
+// The per-class launch of conv_patch_kernel (blockIdx.z = class) reads the input once per class and lets every class write every
+// second pixel of an output row: on the refinement net's big maps that is 11x the algorithmic HBM reads (4 classes x halo, no L2
+// reuse between z planes, read-for-ownership of half-written lines) and 2x the writes (rocprofv3 FETCH_SIZE / WRITE_SIZE).  Here a
+// workgroup stages the union patch of its input pixel tile ((TH+2) x (TW+2), taps dy,dx in {-1,0,+1}) ONCE per K-step, runs the
+// 4 x (4 taps x CKS channels) MFMA groups of all classes on it (4x the MFMAs per staged float), and writes full output rows: a
+// lane owns input pixel (y,x) and stores the pixel PAIRS (2y+py, 2x..2x+1) as 8 bytes, 32 lanes = 256 contiguous bytes.
+// Wave tile 32 channels x 32 pixels per class (TM = TN = 1), accumulators 4 classes x 16 registers.
+// Split-K partials use the layout of the per-class path ([cls][slice][Mpad][P]), so conv_splitk_reduce_kernel finishes them.
+template <int BM, int WM, int WN, int EPT>
+__global__ __launch_bounds__(64 * WM * WN) void deconv4_kernel(PatchArgs a)
+{
+    constexpr int NT = 64 * WM * WN;
+    constexpr int CKS = 4, KD = 16, NG = 8;      // per class: 4 taps x 4 channels
+    constexpr int A4 = 4 * KD * BM / 4;          // float4 chunks of the A tiles of the four classes
+    constexpr int APER = (A4 + NT - 1) / NT;
+    static_assert(BM == WM * 32, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                            // [2][4][KD][BM]
+    float *Ps = smem + 2 * 4 * KD * BM;          // [2][patch_floats]
+    const int patch_floats = a.G * CKS * a.PS;
+
+    const int tid = threadIdx.x;
+    const int zs = blockIdx.z;
+    unsigned bx, by;
+    xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    const int m0 = by * BM;
+    const int tyg = fdiv((int)bx, a.m_tilesx);
+    const int tx = (int)bx - tyg * a.tiles_x;
+    const int tgrp = fdiv(tyg, a.m_tilesy);
+    const int ty = tyg - tgrp * a.tiles_y;
+    const int n0 = tgrp * a.G;
+    const int y_org = ty * a.TH - 1, x_org = tx * a.TW - 1;
+    const float *__restrict__ in0 = a.in + (long)n0 * a.in_n_stride;
+
+    const int plane_elems = a.PH * a.PW;
+    const int nelem = a.G * CKS * plane_elems;
+    int goff[EPT], loff[EPT];
+    unsigned okbits = 0, oklast = 0, wrbits = 0;
+    const int last_c0 = (a.nsteps_total - 1) * CKS;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = tid + i * NT;
+        goff[i] = 0;
+        loff[i] = 0;
+        if (e < nelem) {
+            const int pl = fdiv(e, a.m_plane), pos = e - pl * plane_elems;
+            const int g = pl / CKS, c = pl - g * CKS;
+            const int py = fdiv(pos, a.m_pw), px = pos - py * a.PW;
+            const int gy = y_org + py, gx = x_org + px;
+            const bool ok = ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
+            if (ok) goff[i] = g * (int)a.in_n_stride + c * a.H * a.W + gy * a.W + gx;
+            loff[i] = pl * a.PS + pos;
+            wrbits |= 1u << i;
+            okbits |= (ok ? 1u : 0u) << i;
+            oklast |= ((ok && last_c0 + c < a.Cin) ? 1u : 0u) << i;
+        }
+    }
+    // A loader: chunk q of the [cls][KD][BM/4] tiles; row r = tap*CKS + cl  <->  packed row tap*Cin + c0 + cl of class cls
+    long aoff[APER];
+#pragma unroll
+    for (int i = 0; i < APER; ++i) {
+        const int q = tid + i * NT;
+        const int cls = q / (KD * BM / 4), qq = q - cls * (KD * BM / 4);
+        const int r = qq / (BM / 4), c4 = qq - r * (BM / 4);
+        aoff[i] = (long)cls * a.cls_w_stride + (long)((r / CKS) * a.Cin + (r % CKS)) * a.Mpad + m0 + c4 * 4;
+    }
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tile_pixels = a.G * a.TH * a.TW;
+    int pj = wn * 32 + l31;
+    const bool pvalid = pj < tile_pixels;
+    if (!pvalid) pj = 0;
+    const int pg = fdiv(pj, a.m_thtw), prem = pj - pg * (a.TH * a.TW);
+    const int ppy = fdiv(prem, a.m_tw), ppx = prem - ppy * a.TW;
+    const int bbase = 4 * (pg * CKS * a.PS + ppy * a.PW + ppx + lhi * a.PS);
+
+    floatx16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.0f;
+
+    float pregA[EPT], pregB[EPT];
+    floatx4 aregA[APER], aregB[APER];
+    auto load_patch_one = [&](float (&preg)[EPT], int i, const float *__restrict__ base) {
+        if ((wrbits >> i) & 1u) preg[i] = base[goff[i]];
+    };
+    auto load_a_one = [&](floatx4 (&areg)[APER], int i, const float *__restrict__ base) {
+        if (A4 % NT == 0 || tid + i * NT < A4) areg[i] = *reinterpret_cast<const floatx4 *>(base + aoff[i]);
+    };
+    auto store_tiles = [&](const float (&preg)[EPT], const floatx4 (&areg)[APER], int buf, unsigned ok) {
+        float *P = Ps + buf * patch_floats;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i)
+            if ((wrbits >> i) & 1u) P[loff[i]] = ((ok >> i) & 1u) ? preg[i] : 0.0f;
+        float *A = As + buf * (4 * KD * BM);
+#pragma unroll
+        for (int i = 0; i < APER; ++i)
+            if (A4 % NT == 0 || tid + i * NT < A4) *reinterpret_cast<floatx4 *>(A + (tid + i * NT) * 4) = areg[i];
+    };
+    auto kstep = [&](int buf, int next, float (&preg)[EPT], floatx4 (&areg)[APER], auto prefetch) {
+        constexpr bool PREFETCH = decltype(prefetch)::value;
+        const char *Pb = reinterpret_cast<const char *>(Ps + buf * patch_floats) + bbase;
+        const float *A = As + buf * (4 * KD * BM) + wm * 32 + l31;
+        const float *__restrict__ pbase = in0 + (long)next * CKS * a.H * a.W;
+        const float *__restrict__ abase = a.wp + (long)next * CKS * a.Mpad;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float av[NG], bv[NG];
+#pragma unroll
+            for (int kk = 0; kk < NG; ++kk) {
+                const int k = 2 * kk + lhi;
+                av[kk] = A[(c * KD + k) * BM];
+                // k pair kk = tap kk/2, channels 2*(kk&1) + lhi (lhi is part of bbase)
+                bv[kk] = *reinterpret_cast<const float *>(Pb + 4 * ((2 * (kk & 1)) * a.PS + a.tapoff[c][kk >> 1]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g], bv[g], acc[c], 0, 0, 0);
+                if (PREFETCH && c < 2) {  // the loads of step s+2 ride behind the MFMAs of the first two classes
+                    constexpr int SL = 2 * NG;
+                    const int slot = c * NG + g;
+#pragma unroll
+                    for (int i = slot * EPT / SL; i < (slot + 1) * EPT / SL; ++i) load_patch_one(preg, i, pbase);
+#pragma unroll
+                    for (int i = slot * APER / SL; i < (slot + 1) * APER / SL; ++i) load_a_one(areg, i, abase);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
+    const int s_begin = zs * per_slice;
+    const int nsteps = min(a.nsteps_total, s_begin + per_slice) - s_begin;
+    auto okmask_of = [&](int step) { return step == a.nsteps_total - 1 ? oklast : okbits; };
+    auto phys = [&](int x) { return s_begin + min(x, nsteps - 1); };
+    if (nsteps > 0) {
+        const int p0s = phys(0);
+        const float *__restrict__ pbase = in0 + (long)p0s * CKS * a.H * a.W;
+        const float *__restrict__ abase = a.wp + (long)p0s * CKS * a.Mpad;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) load_patch_one(pregA, i, pbase);
+#pragma unroll
+        for (int i = 0; i < APER; ++i) load_a_one(aregA, i, abase);
+        if (nsteps > 1) {
+            const int s1 = phys(1);
+            const float *__restrict__ pbase1 = in0 + (long)s1 * CKS * a.H * a.W;
+            const float *__restrict__ abase1 = a.wp + (long)s1 * CKS * a.Mpad;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) load_patch_one(pregB, i, pbase1);
+#pragma unroll
+            for (int i = 0; i < APER; ++i) load_a_one(aregB, i, abase1);
+        }
+        store_tiles(pregA, aregA, 0, okmask_of(p0s));
+    }
+    __syncthreads();
+    int s = 0;
+    for (; s + 2 < nsteps; s += 2) {
+        kstep(0, phys(s + 2), pregA, aregA, std::true_type{});
+        store_tiles(pregB, aregB, 1, okmask_of(phys(s + 1)));
+        __syncthreads();
+        kstep(1, phys(s + 3), pregB, aregB, std::true_type{});
+        store_tiles(pregA, aregA, 0, okmask_of(phys(s + 2)));
+        __syncthreads();
+    }
+    if (s + 1 < nsteps) {
+        kstep(0, 0, pregA, aregA, std::false_type{});
+        store_tiles(pregB, aregB, 1, okmask_of(phys(s + 1)));
+        __syncthreads();
+        ++s;
+    }
+    if (nsteps > 0) kstep(s & 1, 0, pregA, aregA, std::false_type{});
+
+    // ---- epilogue: lane = input pixel (y, x) of the tile
+    const int y = ty * a.TH + ppy, x = tx * a.TW + ppx, n = n0 + pg;
+    if (!pvalid || y >= a.Hp || x >= a.Wp || n >= a.N) return;
+    if (a.ksplit > 1) {
+        const long Ptot = (long)a.N * a.Hp * a.Wp;
+        const long p = ((long)n * a.Hp + y) * a.Wp + x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float *__restrict__ ws = a.ws + (((long)c * a.ksplit + zs) * a.Mpad) * Ptot + p;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                ws[(long)co * Ptot] = acc[c][r];
+            }
+        }
+        return;
+    }
+    const long plane = (long)a.Ho * a.Wo;
+    float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)(2 * y) * a.Wo + 2 * x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (co < a.Cout) {
+            const float b = a.bias[co];
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                float v0 = acc[2 * py][r] + b, v1 = acc[2 * py + 1][r] + b;
+                if (a.act) {
+                    v0 = v0 >= 0.0f ? v0 : 0.1f * v0;
+                    v1 = v1 >= 0.0f ? v1 : 0.1f * v1;
+                }
+                float2 v = {v0, v1};
+                *reinterpret_cast<float2 *>(ob + (long)co * plane + (long)py * a.Wo) = v;
+            }
+        }
+    }
+}
+
 // ---- host side --------------------------------------------------------------------------------------
 struct PatchTile { int bm, bn, threads; };
-static const PatchTile kPatchTiles[PTILE_COUNT] = {{128, 128, 256}, {64, 128, 256}, {32, 128, 256}, {64, 64, 256}, {128, 64, 256}, {32, 64, 128}, {16, 128, 256}};
+static const PatchTile kPatchTiles[PTILE_COUNT] = {{128, 128, 256}, {64, 128, 256}, {32, 128, 256}, {64, 64, 256}, {128, 64, 256}, {32, 64, 128}, {16, 128, 256}, {32, 128, 256}, {64, 64, 256}};
+
+bool patch_tile_is_dc4(int tile) { return tile == PTILE_DC4_32x128 || tile == PTILE_DC4_64x64; }
 
 int patch_cks(int ntaps, int tile)
 {
+    if (patch_tile_is_dc4(tile)) return ntaps == 4 ? 4 : 0;
     if (kPatchTiles[tile].bm == 16) return ntaps == 9 ? 4 : 0;  // 16-row MFMA tile: 3x3 heads only (K groups of 4 channels)
     switch (ntaps) {
         case 3: return 8;
@@ -346,7 +568,8 @@ int patch_tile_mtiles(int tile, int Cout, int Mpad) { return kPatchTiles[tile].b
 size_t patch_lds_bytes(int tile, int ntaps, int G, int PS)
 {
     const int cks = patch_cks(ntaps, tile);
-    return sizeof(float) * (2ul * ntaps * cks * kPatchTiles[tile].bm + 2ul * G * cks * PS);
+    const size_t a_tiles = patch_tile_is_dc4(tile) ? 4 : 1;  // the fused transposed conv stages the weights of its four classes
+    return sizeof(float) * (2ul * a_tiles * ntaps * cks * kPatchTiles[tile].bm + 2ul * G * cks * PS);
 }
 
 template <int BM, int WM, int WN, int TM, int TN, int EPT>
@@ -361,6 +584,16 @@ static void launch_patch_taps(const PatchArgs &a, int ntaps, dim3 grid, size_t l
         case 9: hipLaunchKernelGGL((conv_patch_kernel<BM, WM, WN, TM, TN, 9, 2, EPT>), grid, dim3(NT), lds, s, a); break;
         default: break;
     }
+}
+
+template <int BM, int WM, int WN>
+static void launch_dc4(const PatchArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    const long elems = (long)a.G * 4 * a.PH * a.PW;
+    const int per_thread = (int)((elems + 64 * WM * WN - 1) / (64 * WM * WN));
+    if (per_thread <= 2) hipLaunchKernelGGL((deconv4_kernel<BM, WM, WN, 2>), grid, dim3(64 * WM * WN), lds, s, a);
+    else if (per_thread <= 4) hipLaunchKernelGGL((deconv4_kernel<BM, WM, WN, 4>), grid, dim3(64 * WM * WN), lds, s, a);
+    else hipLaunchKernelGGL((deconv4_kernel<BM, WM, WN, PATCH_EPT>), grid, dim3(64 * WM * WN), lds, s, a);
 }
 
 template <int EPT>
@@ -385,6 +618,12 @@ void launch_conv_patch(const PatchArgs &a, int tile, int ntaps, int nclasses, hi
     dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)patch_tile_mtiles(tile, a.Cout, a.Mpad), (unsigned)(nclasses * a.ksplit));
     const size_t lds = patch_lds_bytes(tile, ntaps, a.G, a.PS);
     const int cks = patch_cks(ntaps, tile);
+    if (patch_tile_is_dc4(tile)) {
+        grid.z = (unsigned)a.ksplit;  // the classes are a loop inside the workgroup
+        if (tile == PTILE_DC4_32x128) launch_dc4<32, 1, 4>(a, grid, lds, stream);
+        else launch_dc4<64, 2, 2>(a, grid, lds, stream);
+        return;
+    }
     switch (tile) {
         case PTILE_128x128: launch_patch_ept<128, 2, 2, 2, 2>(a, ntaps, cks, grid, lds, stream); break;
         case PTILE_64x128:  launch_patch_ept<64, 2, 2, 1, 2>(a, ntaps, cks, grid, lds, stream); break;

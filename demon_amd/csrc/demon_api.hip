@@ -284,6 +284,9 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
         if (only_tile >= 0 && tile != only_tile) continue;
         const int bm = patch_tile_bm(tile), bn = patch_tile_bn(tile), nt = patch_tile_threads(tile);
         if (L->Mpad % bm) continue;
+        const bool dc4 = patch_tile_is_dc4(tile);  // all four classes of a transposed conv in one workgroup
+        if (dc4 && (L->kind != Layer::DECONV || only_tile < 0)) continue;  // chosen by the autotuner / a plan only
+        if (dc4) { ext_y = 3; ext_x = 3; } else if (L->kind == Layer::DECONV) { ext_y = 2; ext_x = 2; }
         // the 16-row MFMA tile is for Cout <= 16 heads, and there it replaces the 32-row tiles (half of their MFMA rows are zeros)
         const bool m16_ok = L->Cout <= 16 && patch_cks(ntaps, PTILE_16x128) != 0;
         if (only_tile < 0 && (bm == 16) != m16_ok) continue;
@@ -330,12 +333,13 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
     a.Cout = L->Cout; a.Mpad = L->Mpad; a.cls_w_stride = ca.cls_w_stride;
     a.Ho = ca.Ho; a.Wo = ca.Wo; a.out_n_stride = ca.out_n_stride; a.osy = ca.osy; a.osx = ca.osx;
     a.act = L->act; a.nsteps_total = chunks; a.xcd = ca.xcd;
+    const bool fused_classes = patch_tile_is_dc4(pp.tile);
     for (int cls = 0; cls < 4; ++cls) {
         if (L->kind == Layer::DECONV) {
             static const int tap_d[2][2] = {{0, -1}, {1, 0}};
             const int py = cls >> 1, px = cls & 1;
-            a.oy0[cls] = py ? 0 : -1;
-            a.ox0[cls] = px ? 0 : -1;
+            a.oy0[cls] = fused_classes ? -1 : (py ? 0 : -1);  // fused: one union patch with origin (-1, -1) for all classes
+            a.ox0[cls] = fused_classes ? -1 : (px ? 0 : -1);
             for (int ty = 0; ty < 2; ++ty)
                 for (int tx = 0; tx < 2; ++tx)
                     a.tapoff[cls][ty * 2 + tx] = (tap_d[py][ty] - a.oy0[cls]) * a.PW + (tap_d[px][tx] - a.ox0[cls]);
@@ -348,7 +352,7 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
     }
     // split-K over channel chunks when the grid is too small to fill the chip
     const long groups = (n + a.G - 1) / a.G;
-    const long wgs = groups * a.tiles_y * a.tiles_x * patch_tile_mtiles(pp.tile, L->Cout, L->Mpad) * L->ncls;
+    const long wgs = groups * a.tiles_y * a.tiles_x * patch_tile_mtiles(pp.tile, L->Cout, L->Mpad) * (fused_classes ? 1 : L->ncls);
     int split = 1;
     if (wgs < 384) {
         split = (int)((512 + wgs - 1) / wgs);

@@ -114,7 +114,8 @@ struct PatchArgs {
     // magic numbers for exact unsigned division of the small prologue indices: n / d == mulhi(n, ceil(2^32 / d)) for n < 2^20, d < 2^12
     unsigned m_plane, m_pw, m_thtw, m_tw, m_tilesx, m_tilesy;
 };
-enum PatchTileId { PTILE_128x128 = 0, PTILE_64x128, PTILE_32x128, PTILE_64x64, PTILE_128x64, PTILE_32x64, PTILE_16x128, PTILE_COUNT };
+enum PatchTileId { PTILE_128x128 = 0, PTILE_64x128, PTILE_32x128, PTILE_64x64, PTILE_128x64, PTILE_32x64, PTILE_16x128, PTILE_DC4_32x128, PTILE_DC4_64x64, PTILE_COUNT };
+bool patch_tile_is_dc4(int tile);  // fused 4-class transposed-conv kernel (deconv4_kernel)
 int patch_cks(int ntaps, int tile);   // channels per K-step; 0: this tile has no kernel for ntaps
 int patch_tile_mtiles(int tile, int Cout, int Mpad);  // workgroups along Cout
 int patch_tile_bm(int tile);

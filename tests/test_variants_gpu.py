@@ -20,6 +20,7 @@ LAYERS = [
     ("conv", 4, 32, 3, 3, 1, 1, 40, 72), ("conv", 5, 32, 9, 1, 2, 1, 48, 64), ("conv", 3, 20, 3, 3, 1, 1, 17, 33), ("conv", 6, 32, 1, 9, 1, 2, 24, 128),
     ("conv", 64, 16, 3, 3, 1, 1, 48, 64), ("conv", 64, 16, 3, 3, 1, 1, 21, 37), ("conv", 30, 12, 3, 3, 2, 2, 24, 32),
     ("deconv", 512, 256, 0, 0, 0, 0, 6, 8), ("deconv", 514, 128, 0, 0, 0, 0, 12, 16), ("deconv", 128, 32, 0, 0, 0, 0, 24, 32),
+    ("deconv", 128, 64, 0, 0, 0, 0, 17, 35), ("deconv", 4, 2, 0, 0, 0, 0, 6, 8), ("deconv", 30, 40, 0, 0, 0, 0, 9, 50),
 ]
 
 
@@ -47,7 +48,7 @@ def test_all_variants_agree(gpu_ctx, layer):
         w = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
     b = rng.standard_normal((cout,)).astype(np.float32)
     want = _ref(kind, x, w, b, (sh, sw))
-    plans = [(3, 0, 0)] + [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(7) for ks in (0, 2, 3, 5)]
+    plans = [(3, 0, 0)] + [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(9) for ks in (0, 2, 3, 5)]
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
