@@ -51,6 +51,11 @@ struct Step {
     // iterative nets only: 1 = conv1 / conv2 (depend on image_pair and weights only, identical in every iteration);
     // 2 = copy of the cached conv2 output into the concat buffer (runs instead of them when the option is on)
     int image_only = 0;
+    // Side branch: small kernel chains that do not depend on the steps that follow them on the main stream (the motion head next
+    // to the decoder of the depth+motion block, predict_flow5 -> upsample next to refine4 of the flow block) run on a second
+    // stream.  side = 1 marks them; fork = 1 on the first one (side stream waits for everything enqueued so far on the main
+    // stream); join = 1 on the first MAIN step that needs their results (main stream waits for the side stream).
+    int side = 0, fork = 0, join = 0;
 };
 
 struct Variable {
@@ -81,6 +86,10 @@ struct demon_ctx {
     View image_pair, image2_2, flowconf5, flowconf2, depth2, normal2, depth0, normal0;
     float *d_rot = nullptr, *d_trans = nullptr, *d_scale = nullptr, *d_motion = nullptr, *d_intrinsics = nullptr;
     float *d_ws = nullptr;  // split-K workspace
+    float *d_ws_side = nullptr;  // split-K workspace of the side branch (runs concurrently with the main one)
+    hipStream_t side_stream = nullptr;
+    std::vector<hipEvent_t> events;  // fork / join events, one per use inside a sequence
+    int opt_side_branches = 1;
 };
 
 namespace {
@@ -526,6 +535,12 @@ struct Builder {
     // false: helpers.py:70-153 zero-pad k//2 on both sides then VALID; true: v2/helpers.py:24-91 padding='same', which for the
     // even input sizes of this net puts (k - stride) // 2 zeros in front and the rest behind
     bool same = false;
+    int side = 0, fork_next = 0, join_next = 0;  // see Step::side
+    void stamp(Step &st)
+    {
+        st.side = side; st.fork = fork_next; st.join = join_next;
+        fork_next = 0; join_next = 0;
+    }
 
     Layer *make(const std::string &name, Layer::Kind kind, View in, View out, int kh, int kw, int sh, int sw, int act,
                 const float *scale = nullptr, bool add_step = true)
@@ -553,10 +568,10 @@ struct Builder {
         st.flops_per_sample = 2.0 * out.C * kreal * pix;
         st.bytes_per_sample = 4.0 * ((double)in.C * in.H * in.W + (double)out.C * out.H * out.W);
         st.bytes_fixed = 4.0 * ((double)p->K * p->ncls * out.C + out.C);
-        float *ws = c->d_ws;
+        float *ws = side ? c->d_ws_side : c->d_ws;
         st.fn = [p, ws](int n, hipStream_t s) { run_layer(p, n, s, ws); };
         st.image_only = tag;
-        if (add_step) steps->push_back(st);
+        if (add_step) { stamp(st); steps->push_back(st); }
         return p;
     }
     // helpers.py:70-102
@@ -587,6 +602,7 @@ struct Builder {
         st.bytes_per_sample = bytes_per_sample;
         st.fn = std::move(fn);
         st.image_only = tag;
+        stamp(st);
         steps->push_back(st);
     }
 };
@@ -657,12 +673,18 @@ void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope
     View feat5 = buffer(c, "conv5_1", v2 ? ep.c5 + 96 : ep.c5, h5, w5);  // v2: [conv5_1 384, dense5 96] (v2/blocks.py:213)
     View conv5_1 = feat5.slice(0, ep.c5);
     if (iterative) b.tag = 1;
+    const size_t block_begin = steps->size();
     b.conv2("conv1", c->image_pair, conv1, 9, 2, ep.c1y);
     if (!iterative) {
         b.conv2("conv2", conv1, conv2cat, 7, 2, ep.c2y_boot);  // 64 outputs (:144; v2 :144 (48,64))
     } else {
         b.conv2("conv2", conv1, conv2cat.slice(0, 32), 7, 2);
         add_image_cache_steps(b, "flow2_conv2_cache", conv2cat.slice(0, 32));
+        // side branch: the extra-input chain (previous depth / motion -> flow -> warp -> conv2_extra_inputs: five small launches)
+        // does not depend on conv1 / conv2, which see only the images; it is enqueued in front of them and joins at conv2_1
+        std::vector<Step> side_steps;
+        b.steps = &side_steps;
+        b.side = 1; b.fork_next = 1;
         View extra = buffer(c, "extra_flow", 9, h2, w2);  // [warped 3, flow 2, depth 1, normal 3] (:180; v2 :180)
         View img2 = c->image2_2, depth2 = c->depth2, normal2 = c->normal2;
         float *rot = c->d_rot, *trans = c->d_trans, *intr = c->d_intrinsics;
@@ -682,6 +704,10 @@ void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope
                                  (long)h2 * w2, s);
         });
         b.conv2("conv2_extra_inputs", extra, conv2cat.slice(32, 32), 3, 1);
+        b.side = 0;
+        b.steps = steps;
+        steps->insert(steps->begin() + block_begin, side_steps.begin(), side_steps.end());
+        b.join_next = 1;
     }
     b.conv2("conv2_1", conv2cat, concat2.slice(64, 64), 3, 1);
     b.conv2("conv3", concat2.slice(64, 64), conv3, 5, 2, ep.c3y);
@@ -692,10 +718,15 @@ void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope
     b.conv2("conv5_1", conv5, conv5_1, 3, 1);
     if (v2) add_dense5(b, feat5);
     View pf5 = buffer(c, "predict5_tmp", 24, h5, w5);
+    // side branch: the level-5 flow head and its upsampling (three launches on a 6x8 map) next to refine4/upconv; refine3/upconv
+    // reads the whole concat4 buffer, so it joins
+    b.side = 1; b.fork_next = 1;
     b.conv("predict_flow5/conv1", feat5, pf5, 3, 1, 1);
     b.conv("predict_flow5/conv2", pf5, c->flowconf5, 3, 1, 0);
     b.deconv("upsample_flow5to4/upconv", c->flowconf5, concat4f.slice(512, 2), 0);
+    b.side = 0;
     b.deconv("refine4/upconv", feat5, concat4f.slice(0, 256), 1);
+    b.join_next = 1;
     b.deconv("refine3/upconv", concat4f, concat3.slice(0, 128), 1);
     b.deconv("refine2/upconv", concat3, concat2.slice(0, 64), 1);
     View pf2 = buffer(c, "predict2_tmp", 24, h2, w2);
@@ -723,9 +754,15 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
     View feat5 = buffer(c, "conv5_1", v2 ? ep.c5 + 96 : ep.c5, h5, w5);
     View conv5_1 = feat5.slice(0, ep.c5);
     if (iterative) b.tag = 1;
+    const size_t block_begin = steps->size();
     b.conv2("conv1", c->image_pair, conv1, 9, 2, ep.c1y);
     b.conv2("conv2", conv1, conv2cat.slice(0, 32), 7, 2);
     if (iterative) add_image_cache_steps(b, "dm2_conv2_cache", conv2cat.slice(0, 32));
+    b.tag = 0;
+    // side branch (as in the flow block): warp / flow_to_depth / conv2_extra_inputs next to conv1 / conv2, joined at conv2_1
+    std::vector<Step> side_steps;
+    b.steps = &side_steps;
+    b.side = 1; b.fork_next = 1;
     const int nextra = iterative ? 8 : 7;  // [warped 3, flowconf 4, depth_from_flow 1] (:341, :362; v2 :359, :381)
     View extra = buffer(c, iterative ? "extra_dm8" : "extra_dm7", nextra, h2, w2);
     View img2 = c->image2_2, flowconf2 = c->flowconf2;
@@ -748,6 +785,10 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
         });
     }
     b.conv2("conv2_extra_inputs", extra, conv2cat.slice(32, 32), 3, 1);
+    b.side = 0;
+    b.steps = steps;
+    steps->insert(steps->begin() + block_begin, side_steps.begin(), side_steps.end());
+    b.join_next = 1;
     b.conv2("conv2_1", conv2cat, concat2.slice(64, 64), 3, 1);
     b.conv2("conv3", concat2.slice(64, 64), conv3, 5, 2, ep.c3y);
     b.conv2("conv3_1", conv3, concat3.slice(128, 128), 3, 1);
@@ -757,6 +798,9 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
     b.conv2("conv5_1", conv5, conv5_1, 3, 1);
     // motion head (:380-412; v2 :413-457); flatten is C,H,W order = NCHW memory order
     View mconv = buffer(c, "motion_conv1", 128, h5, w5);
+    // side branch: the whole motion head (small maps, dense layers) next to the decoder; predict_depthnormal2/conv2 needs the
+    // predicted scale, so it joins.  The branch has its own split-K workspace.
+    b.side = 1; b.fork_next = 1;
     if (!v2) {
         b.conv("motion_conv1", conv5_1, mconv, 3, 1, 1);
     } else {
@@ -784,12 +828,14 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
             launch_motion_tail(x, L2->d_wp, L2->d_bias, L3->d_wp, L3->d_bias, motion, rot, trans, scale, n, 1024, L2->Mpad, L3->Mpad, s);
         });
     }
+    b.side = 0;
     b.deconv("refine4/upconv", conv5_1, concat4.slice(0, 256), 1);  // v2 too: conv5_1 without dense5 (v2/blocks.py:462)
     b.deconv("refine3/upconv", concat4, concat3.slice(0, 128), 1);
     b.deconv("refine2/upconv", concat3, concat2.slice(0, 64), 1);
     View pd = buffer(c, "predict2_tmp", 24, h2, w2);
     View dn = buffer(c, "depthnormal2", 4, h2, w2);  // ch 0 = scale*depth, ch 1:4 = normal (:278-287; v2 :294-305)
     b.conv("predict_depthnormal2/conv1", concat2, pd, 3, 1, 1);
+    b.join_next = 1;
     b.conv("predict_depthnormal2/conv2", pd, dn, 3, 1, 0, c->d_scale);
     if (!b.ok) c->err = "device allocation failed while building " + scope;
 }
@@ -838,13 +884,33 @@ bool weights_ready(demon_ctx *c, std::string *missing)
 
 // mode 0: plain (every layer, no cache traffic); 1: first iteration with the option on (layers + save); 2: later iterations
 // (cached conv2 output instead of the image-only layers)
-void run_steps(const std::vector<Step> &steps, int n, hipStream_t s, int mode = 0)
+void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t s, int mode, size_t &ev)
 {
+    const bool branches = c->opt_side_branches && c->side_stream && s == c->stream;
+    bool side_open = false;  // work on the side stream that the main stream has not waited for yet
     for (const Step &st : steps) {
         if (st.image_only == 1 && mode == 2) continue;
         if (st.image_only == 2 && mode != 2) continue;
         if (st.image_only == 3 && mode != 1) continue;
-        st.fn(n, s);
+        if (!branches) { st.fn(n, s); continue; }
+        if (st.fork && ev < c->events.size()) {
+            hipEventRecord(c->events[ev], s);
+            hipStreamWaitEvent(c->side_stream, c->events[ev], 0);
+            ++ev;
+            side_open = true;
+        }
+        if (st.join && side_open && ev < c->events.size()) {
+            hipEventRecord(c->events[ev], c->side_stream);
+            hipStreamWaitEvent(s, c->events[ev], 0);
+            ++ev;
+            side_open = false;
+        }
+        st.fn(n, (st.side && side_open) ? c->side_stream : s);
+    }
+    if (side_open && ev < c->events.size()) {  // never leave the side stream dangling (a capture must be joined)
+        hipEventRecord(c->events[ev], c->side_stream);
+        hipStreamWaitEvent(s, c->events[ev], 0);
+        ++ev;
     }
 }
 
@@ -852,11 +918,12 @@ enum SeqKind { SEQ_BOOT = 0, SEQ_ITER, SEQ_REFINE, SEQ_FULL };
 
 void enqueue_sequence(demon_ctx *c, int kind, int n, int iterations, hipStream_t s)
 {
-    if (kind == SEQ_BOOT || kind == SEQ_FULL) run_steps(c->net_boot, n, s);
-    if (kind == SEQ_ITER) run_steps(c->net_iter, n, s);
+    size_t ev = 0;  // every fork / join of the sequence takes its own event
+    if (kind == SEQ_BOOT || kind == SEQ_FULL) run_steps(c, c->net_boot, n, s, 0, ev);
+    if (kind == SEQ_ITER) run_steps(c, c->net_iter, n, s, 0, ev);
     if (kind == SEQ_FULL)
-        for (int i = 0; i < iterations; ++i) run_steps(c->net_iter, n, s, c->opt_reuse_image ? (i == 0 ? 1 : 2) : 0);
-    if (kind == SEQ_REFINE || kind == SEQ_FULL) run_steps(c->net_refine, n, s);
+        for (int i = 0; i < iterations; ++i) run_steps(c, c->net_iter, n, s, c->opt_reuse_image ? (i == 0 ? 1 : 2) : 0, ev);
+    if (kind == SEQ_REFINE || kind == SEQ_FULL) run_steps(c, c->net_refine, n, s, 0, ev);
 }
 
 // one hipGraph per (sequence, batch, iterations): the whole kernel chain becomes a single launch
@@ -868,7 +935,7 @@ int run_sequence(demon_ctx *c, int kind, int n, int iterations)
         return DEMON_OK;
     }
     char key[64];
-    snprintf(key, sizeof key, "%d:%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method, c->opt_reuse_image);
+    snprintf(key, sizeof key, "%d:%d:%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method, c->opt_reuse_image, c->opt_side_branches);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -981,6 +1048,12 @@ static int create_impl(demon_ctx **out, int device, int max_batch, int height, i
     p->d_motion = dev_alloc(p, sizeof(float) * 7 * max_batch);
     p->d_intrinsics = dev_alloc(p, sizeof(float) * 4 * max_batch);
     p->d_ws = dev_alloc(p, sizeof(float) * kSplitKWorkspaceFloats);
+    p->d_ws_side = dev_alloc(p, sizeof(float) * kSplitKWorkspaceFloats);
+    if (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess) p->side_stream = nullptr;
+    p->events.resize(256);  // 4 per pass of the flow + depth/motion blocks; a 30-iteration sequence still fits
+    for (hipEvent_t &e : p->events)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; }
+    if (!p->d_ws_side) p->d_ws_side = p->d_ws, p->opt_side_branches = 0;
     if (!p->d_ws || !p->d_rot || !p->d_trans || !p->d_scale || !p->d_motion || !p->d_intrinsics) {
         demon_destroy(c.release());
         return fail(nullptr, DEMON_ERR_HIP, "device allocation failed");
@@ -1025,6 +1098,8 @@ int demon_destroy(demon_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    for (hipEvent_t e : c->events) if (e) hipEventDestroy(e);
     for (void *p : c->allocations) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1109,6 +1184,7 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
         return DEMON_OK;
     }
     if (!strcmp(key, "reuse_image_features")) { c->opt_reuse_image = value ? 1 : 0; return DEMON_OK; }
+    if (!strcmp(key, "side_branches")) { c->opt_side_branches = (value && c->side_stream && c->d_ws_side != c->d_ws) ? 1 : 0; return DEMON_OK; }
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }
 
