@@ -217,3 +217,33 @@ def test_reuse_image_features_option_is_exact(gpu_ctx):
     for k in KEYS + ("predict_depth0",):
         np.testing.assert_array_equal(fast[k], base[k])
     assert np.isfinite(one["predict_depth0"]).all()
+
+
+def test_side_branches_are_exact(gpu_ctx):
+    """second-stream side branches (motion head, level-5 flow head, extra-input chains; fork / join by events, captured into
+    the hipGraph): same kernels on the same data -> bit-identical outputs with the option on / off, graph / eager, and
+    together with reuse_image_features; staged calls (bootstrap / iterative / refine) use them too"""
+    pair, img2_2 = make_inputs(3, seed=15)
+    results = {}
+    try:
+        for side in (1, 0):
+            for graph in (1, 0):
+                for reuse in (0, 1):
+                    gpu_ctx.set_option("side_branches", side)
+                    gpu_ctx.set_option("hipgraph", graph)
+                    gpu_ctx.set_option("reuse_image_features", reuse)
+                    results[(side, graph, reuse)] = gpu_ctx.full(pair, img2_2, iterations=3)
+        gpu_ctx.set_option("side_branches", 1); gpu_ctx.set_option("hipgraph", 1); gpu_ctx.set_option("reuse_image_features", 0)
+        r = gpu_ctx.bootstrap(pair, img2_2)
+        for _ in range(3):
+            r = gpu_ctx.iterative(pair, img2_2, r["predict_depth2"], r["predict_normal2"], r["predict_rotation"], r["predict_translation"])
+    finally:
+        gpu_ctx.set_option("side_branches", 1)
+        gpu_ctx.set_option("hipgraph", 1)
+        gpu_ctx.set_option("reuse_image_features", 0)
+    ref = results[(0, 0, 0)]
+    for key, got in results.items():
+        for k in KEYS + ("predict_depth0",):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="%s %s" % (key, k))
+    for k in KEYS:
+        np.testing.assert_array_equal(r[k], ref[k])
