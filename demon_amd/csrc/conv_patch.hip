@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
             const int gy = y_org + py, gx = x_org + px;
             const bool ok = ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
             if (ok) goff[i] = g * (int)a.in_n_stride + c * a.H * a.W + gy * a.W + gx;
-            loff[i] = pl * a.PS + pos;
+            loff[i] = pl * a.PS + py * a.PWL + px;
             wrbits |= 1u << i;
             okbits |= (ok ? 1u : 0u) << i;
             oklast |= ((ok && last_c0 + c < a.Cin) ? 1u : 0u) << i;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
         if (pj >= tile_pixels) pj = 0;  // padding lanes read a valid address; masked at the store
         const int g = fdiv(pj, a.m_thtw), rem = pj - g * (a.TH * a.TW);
         const int py = fdiv(rem, a.m_tw), px = rem - py * a.TW;
-        bbase[j] = 4 * (g * CKS * a.PS + py * a.sh * a.PW + px * a.sw + lhi * a.PS);
+        bbase[j] = 4 * (g * CKS * a.PS + py * a.sh * a.PWL + px * a.sw + lhi * a.PS);
     }
     int so[NG];  // per k group: (first channel of the group)*PS + tap offset, bytes (wave uniform)
 #pragma unroll
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64 * WM * WN) void deconv4_kernel(PatchArgs a)
             const int gy = y_org + py, gx = x_org + px;
             const bool ok = ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
             if (ok) goff[i] = g * (int)a.in_n_stride + c * a.H * a.W + gy * a.W + gx;
-            loff[i] = pl * a.PS + pos;
+            loff[i] = pl * a.PS + py * a.PWL + px;
             wrbits |= 1u << i;
             okbits |= (ok ? 1u : 0u) << i;
             oklast |= ((ok && last_c0 + c < a.Cin) ? 1u : 0u) << i;
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64 * WM * WN) void deconv4_kernel(PatchArgs a)
     if (!pvalid) pj = 0;
     const int pg = fdiv(pj, a.m_thtw), prem = pj - pg * (a.TH * a.TW);
     const int ppy = fdiv(prem, a.m_tw), ppx = prem - ppy * a.TW;
-    const int bbase = 4 * (pg * CKS * a.PS + ppy * a.PW + ppx + lhi * a.PS);
+    const int bbase = 4 * (pg * CKS * a.PS + ppy * a.PWL + ppx + lhi * a.PS);
 
     floatx16 acc[4];
 #pragma unroll

@@ -343,6 +343,43 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
     a.Ho = ca.Ho; a.Wo = ca.Wo; a.out_n_stride = ca.out_n_stride; a.osy = ca.osy; a.osx = ca.osx;
     a.act = L->act; a.nsteps_total = chunks; a.xcd = ca.xcd;
     const bool fused_classes = patch_tile_is_dc4(pp.tile);
+    {
+        // LDS layout of the patch: row pitch PWL >= PW and plane stride PS >= PH * PWL chosen so that the 32 lanes of one
+        // B-fragment read (32 pixels of the tile; 16 pixels x 2 channels for the 16-row MFMA tile) fall into as many different
+        // banks as possible.  With the natural pitch a tile narrower than 32 pixels puts its rows PW = TW + halo floats apart and
+        // neighbouring rows collide (rocprofv3 SQ_LDS_BANK_CONFLICT: 27-35 % of the LDS cycles of this kernel).
+        static const int pad_enabled = getenv("DEMON_LDS_PAD") ? atoi(getenv("DEMON_LDS_PAD")) : 1;
+        const bool m16 = patch_tile_bm(pp.tile) == 16;
+        const int pxw = m16 ? 16 : 32, cks = patch_cks(ntaps, pp.tile);
+        const int tile_pixels = a.G * a.TH * a.TW, blocks = (tile_pixels + pxw - 1) / pxw;
+        long best = -1;
+        int best_p = 0, best_q = 0;
+        const int qmax = (m16 || a.G > 1) ? 32 : 1;
+        for (int q = 0; q < qmax && pad_enabled; ++q)
+            for (int p = 0; p < 32; ++p) {
+                const int PWL = a.PW + p, PS = a.PH * PWL + q;
+                if (patch_lds_bytes(pp.tile, ntaps, a.G, PS) > 64 * 1024) continue;
+                long cost = 0;
+                for (int b = 0; b < blocks; ++b) {
+                    int cnt[32] = {0};
+                    int worst = 0;
+                    for (int l = 0; l < 32; ++l) {
+                        int pix = b * pxw + l % pxw;
+                        const int k = m16 ? l / 16 : 0;
+                        if (pix >= tile_pixels) pix = 0;
+                        const int g = pix / (a.TH * a.TW), rem = pix - g * (a.TH * a.TW);
+                        const int py = rem / a.TW, px = rem - py * a.TW;
+                        const int addr = g * cks * PS + py * a.sh * PWL + px * a.sw + k * PS;
+                        if (++cnt[addr & 31] > worst) worst = cnt[addr & 31];
+                    }
+                    cost += worst;
+                }
+                const long score = cost * 100000 + (long)a.G * cks * PS;  // fewest conflicts first, then the smallest patch
+                if (best < 0 || score < best) { best = score; best_p = p; best_q = q; }
+            }
+        a.PWL = a.PW + best_p;
+        a.PS = a.PH * a.PWL + best_q;
+    }
     for (int cls = 0; cls < 4; ++cls) {
         if (L->kind == Layer::DECONV) {
             static const int tap_d[2][2] = {{0, -1}, {1, 0}};
@@ -351,12 +388,12 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
             a.ox0[cls] = fused_classes ? -1 : (px ? 0 : -1);
             for (int ty = 0; ty < 2; ++ty)
                 for (int tx = 0; tx < 2; ++tx)
-                    a.tapoff[cls][ty * 2 + tx] = (tap_d[py][ty] - a.oy0[cls]) * a.PW + (tap_d[px][tx] - a.ox0[cls]);
+                    a.tapoff[cls][ty * 2 + tx] = (tap_d[py][ty] - a.oy0[cls]) * a.PWL + (tap_d[px][tx] - a.ox0[cls]);
         } else {
             a.oy0[cls] = -L->ph;
             a.ox0[cls] = -L->pw;
             for (int ta = 0; ta < L->kh; ++ta)
-                for (int tb = 0; tb < L->kw; ++tb) a.tapoff[cls][ta * L->kw + tb] = ta * a.PW + tb;
+                for (int tb = 0; tb < L->kw; ++tb) a.tapoff[cls][ta * L->kw + tb] = ta * a.PWL + tb;
         }
     }
     // split-K over channel chunks when the grid is too small to fill the chip

@@ -102,7 +102,8 @@ struct PatchArgs {
     int G, TH, TW, tiles_y, tiles_x;  // pixel tile = G images x TH rows x TW cols
     int sh, sw;
     int oy0[4], ox0[4];  // per class: input coordinates of patch element (0,0) relative to the tile anchor
-    int PH, PW, PS;      // patch rows / cols / plane stride (floats)
+    int PH, PW, PS;      // patch rows / cols / plane stride in LDS (floats; PS >= PH * PWL)
+    int PWL;             // row pitch of the patch in LDS (>= PW): padded so that the 32 lanes of a fragment read hit 32 banks
     int tapoff[4][9];    // per class, per tap: float offset inside a plane
     int Cout, Mpad;
     long cls_w_stride;
