@@ -58,6 +58,10 @@ SIGNATURES = {
     "demon_synchronize": (_I, [_P]),
     "demon_download_outputs": (_I, [_P, _I, ctypes.POINTER(DemonOutputs), c_float_p]),
     "demon_download_normal0": (_I, [_P, _I, c_float_p]),
+    "demon_upload_inputs_async": (_I, [_P, _I, c_float_p, c_float_p]),
+    "demon_download_outputs_async": (_I, [_P, _I, ctypes.POINTER(DemonOutputs), c_float_p]),
+    "demon_host_register": (_I, [ctypes.c_void_p, ctypes.c_int64]),
+    "demon_host_unregister": (_I, [ctypes.c_void_p]),
     "demon_time_full": (_I, [_P, _I, _I, _I, c_float_p]),
     "demon_profile_full": (_I, [_P, _I, _I, _I, ctypes.POINTER(LaunchRecord), _I, c_int_p]),
     "demon_op_depth_to_flow": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, _I, _I, _I, _I, _I, _I]),

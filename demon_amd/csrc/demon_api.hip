@@ -1281,6 +1281,38 @@ int demon_upload_inputs(demon_ctx *c, int n, const float *image_pair, const floa
     return DEMON_OK;
 }
 
+// Asynchronous variants for pipelines that overlap the copies of one context with the kernels of another (two contexts, two
+// streams): nothing here waits; host buffers must be page-locked (demon_host_register) and stay valid until demon_synchronize.
+int demon_upload_inputs_async(demon_ctx *c, int n, const float *image_pair, const float *image2_2)
+{
+    int r = check_batch(c, n);
+    if (r) return r;
+    hipSetDevice(c->device);
+    if ((r = h2d(c, c->image_pair, image_pair, n))) return r;
+    return h2d(c, c->image2_2, image2_2, n);
+}
+
+int demon_download_outputs_async(demon_ctx *c, int n, const demon_outputs *o, float *depth0)
+{
+    if (!c || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad batch");
+    hipSetDevice(c->device);
+    int r = download_outputs(c, n, o);
+    if (r) return r;
+    return d2h(c, depth0, c->depth0, n);
+}
+
+int demon_host_register(void *ptr, int64_t bytes)
+{
+    if (!ptr || bytes <= 0) return DEMON_ERR_INVALID;
+    return hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault) == hipSuccess ? DEMON_OK : DEMON_ERR_HIP;
+}
+
+int demon_host_unregister(void *ptr)
+{
+    if (!ptr) return DEMON_ERR_INVALID;
+    return hipHostUnregister(ptr) == hipSuccess ? DEMON_OK : DEMON_ERR_HIP;
+}
+
 int demon_run_full(demon_ctx *c, int n, int iterations)
 {
     int r = check_batch(c, n);

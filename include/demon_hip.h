@@ -115,6 +115,14 @@ int demon_run_full(demon_ctx *ctx, int n, int iterations);
 int demon_run_bootstrap(demon_ctx *ctx, int n);
 int demon_synchronize(demon_ctx *ctx);
 int demon_download_outputs(demon_ctx *ctx, int n, const demon_outputs *out, float *predict_depth0);
+/* Pipelining across contexts (copy / compute overlap): the _async variants only enqueue on the context's stream; the host buffers
+ * must be page-locked (demon_host_register pins an existing allocation, e.g. a numpy array) and stay untouched until
+ * demon_synchronize.  Two contexts fed alternately keep the copy engines busy under the kernels of the other one
+ * (demon_amd/pipeline.py).                                                                                              */
+int demon_upload_inputs_async(demon_ctx *ctx, int n, const float *image_pair, const float *image2_2);
+int demon_download_outputs_async(demon_ctx *ctx, int n, const demon_outputs *out, float *predict_depth0);
+int demon_host_register(void *ptr, int64_t bytes);
+int demon_host_unregister(void *ptr);
 /* v2 contexts only: predict_normal0 [n,3,H,W] of the last refinement run (v2/networks.py:223-226; v2/blocks.py:560-562). */
 int demon_download_normal0(demon_ctx *ctx, int n, float *predict_normal0);
 /* time `steps` back-to-back demon_run_full calls with hip events on the context stream */

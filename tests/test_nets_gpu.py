@@ -247,3 +247,22 @@ def test_side_branches_are_exact(gpu_ctx):
             np.testing.assert_array_equal(got[k], ref[k], err_msg="%s %s" % (key, k))
     for k in KEYS:
         np.testing.assert_array_equal(r[k], ref[k])
+
+
+def test_two_context_pipeline_matches_single_context(gpu_ctx, synth_weights):
+    """demon_amd.pipeline.Pipeline (asynchronous copies on page-locked host arrays, two contexts / streams so that the copies of
+    one batch run under the kernels of another) returns what DemonContext.full returns, batch by batch"""
+    from demon_amd.pipeline import Pipeline
+    pair, img2_2 = make_inputs(12, seed=16)
+    pipe = Pipeline(synth_weights, batch=4)
+    try:
+        got = pipe.run(pair, img2_2, iterations=2)
+        again = pipe.run(pair, img2_2, iterations=2)
+    finally:
+        pipe.close()
+    for i in range(3):
+        want = gpu_ctx.full(pair[4 * i:4 * i + 4], img2_2[4 * i:4 * i + 4], iterations=2)
+        for k in KEYS + ("predict_depth0", "predict_scale"):
+            np.testing.assert_array_equal(got[k][4 * i:4 * i + 4], want[k], err_msg=k)
+    for k in got:
+        np.testing.assert_array_equal(got[k], again[k])
