@@ -37,7 +37,6 @@ struct Layer {
     bool have_kernel = false, have_bias = false;
     std::vector<int64_t> kernel_dims;  // TF layout
     int force_tile = -1, force_split = 0;  // tuning override (demon_bench_layer)
-    int plane_pad = 0;                     // experiment: extra floats between channel planes of in / out
     // autotuned choice per batch size: kind 0 = im2col kernel (tile, ksplit), 1 = patch kernel (patch tile)
     struct Tuned { int kind, tile, ksplit; };
     std::map<int, Tuned> tuned;
@@ -178,7 +177,7 @@ bool plan_layer(demon_ctx *c, Layer *L)
                 for (int ci = 0; ci < L->Cin; ++ci) {
                     const int k = (a * L->kw + b) * L->Cin + ci;
                     const int dy = a - L->ph, dx = b - L->pw;
-                    tab[k] = KEntry{ci * (H * W + L->plane_pad) + dy * W + dx, pack(dy, dx)};
+                    tab[k] = KEntry{ci * H * W + dy * W + dx, pack(dy, dx)};
                 }
     } else if (L->kind == Layer::DECONV) {
         // output (2y+py, 2x+px) of the cropped k4 s2 transposed conv reads input rows
@@ -191,7 +190,7 @@ bool plan_layer(demon_ctx *c, Layer *L)
                     for (int ci = 0; ci < L->Cin; ++ci) {
                         const int k = (ty * 2 + tx) * L->Cin + ci;
                         const int dy = tap_d[py][ty], dx = tap_d[px][tx];
-                        tab[(size_t)cls * L->Kpad + k] = KEntry{ci * (H * W + L->plane_pad) + dy * W + dx, pack(dy, dx)};
+                        tab[(size_t)cls * L->Kpad + k] = KEntry{ci * H * W + dy * W + dx, pack(dy, dx)};
                     }
         }
     } else {
@@ -240,7 +239,6 @@ constexpr long kSplitKWorkspaceFloats = 16l << 20;  // 64 MiB
 void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
 {
     a.ws = ws;
-    a.dbg = 0;
     a.in = L->in.ptr();
     a.out = L->out.ptr();
     a.wp = L->d_wp;
@@ -256,9 +254,8 @@ void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
     a.Kpad = L->Kpad;
     a.Ho = L->out.H;
     a.Wo = L->out.W;
-    a.out_n_stride = L->out.n_stride() + (long)L->plane_pad * L->out.Ctot;
-    a.in_n_stride += (long)L->plane_pad * L->in.Ctot;
-    a.out_plane = (long)L->out.H * L->out.W + L->plane_pad;
+    a.out_n_stride = L->out.n_stride();
+    a.out_plane = (long)L->out.H * L->out.W;
     a.act = L->act;
     a.cls_w_stride = (long)L->Krows * L->Mpad;
     a.ksplit = 1;
@@ -644,10 +641,6 @@ struct Builder {
     }
 };
 
-// shared encoder/decoder tail of the flow and depth+motion blocks
-struct EncDec {
-    View conv2cat, concat2, concat3, concat4, conv5_1;
-};
 
 // Option "reuse_image_features": conv1 / conv2 of netFlow2 and netDM2 see only image_pair and their weights, so they give the
 // same result in all iterations of one forward pass.  After them (tag 1) the result is saved to a cache buffer (tag 3, runs

@@ -72,7 +72,6 @@ struct ConvArgs {
     long cls_w_stride;  // Kpad*Mpad
     float *ws;          // split-K workspace [cls][slice][Mpad][P]
     int ksplit;         // number of K slices (1 = fused epilogue)
-    int dbg;            // ablation switches for tuning experiments (0 in production)
     int xcd;            // 1: XCD-aware tile order (xcd_tile)
     long out_plane;     // elements between output channel planes (Ho*Wo unless the buffer is padded)
 };
