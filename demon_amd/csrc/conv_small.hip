@@ -43,6 +43,23 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallConvArgs a)
         // thread's own four pixels start on a 16-byte boundary.  Index math is shifts only: two rows per pass for the
         // 128 interior columns, then one pass for the two halo columns of every (channel, row).
         {
+            const bool vec = (a.W & 3) == 0 && (hw & 3) == 0 && (a.in_n_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
+            if (vec) {
+                // 16 bytes per lane: 32 lanes cover the 128 interior columns of one (channel, row), 8 of them per pass
+                const int sub = threadIdx.x >> 5, col = (threadIdx.x & 31) * 4;
+                const int gx = x0 + col;
+                const bool xin = gx < a.W;  // W % 4 == 0: a group of four columns is inside or outside as a whole
+                for (int rr = 0; rr < nc * (SM_TH + 2); rr += 8) {
+                    const int q = rr + sub;
+                    if (q < nc * (SM_TH + 2)) {
+                        const int c = q / (SM_TH + 2), row = q - c * (SM_TH + 2);
+                        const int gy = y0 - 1 + row;
+                        floatx4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (xin && gy >= 0 && gy < a.H) v = *reinterpret_cast<const floatx4 *>(inp + (long)(c0 + c) * hw + gy * a.W + gx);
+                        *reinterpret_cast<floatx4 *>(&tile[c][row][col + 4]) = v;
+                    }
+                }
+            } else {
             const int half = threadIdx.x >> 7, col = threadIdx.x & 127;
             const int gx = x0 + col;
             const bool xin = gx < a.W;
@@ -55,6 +72,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallConvArgs a)
                     if (xin && gy >= 0 && gy < a.H) v = inp[(long)(c0 + c) * hw + gy * a.W + gx];
                     tile[c][row][col + 4] = v;
                 }
+            }
             }
             const int q = threadIdx.x >> 1, side = threadIdx.x & 1;
             if (q < nc * (SM_TH + 2)) {
