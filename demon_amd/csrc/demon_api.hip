@@ -10,7 +10,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <array>
 #include <functional>
+#include <mutex>
 #include <map>
 #include <memory>
 #include <string>
@@ -349,33 +351,48 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
         const bool m16 = patch_tile_bm(pp.tile) == 16;
         const int pxw = m16 ? 16 : 32, cks = patch_cks(ntaps, pp.tile);
         const int tile_pixels = a.G * a.TH * a.TW, blocks = (tile_pixels + pxw - 1) / pxw;
-        long best = -1;
+        // the search is pure host arithmetic but runs on every eager launch: memoised per geometry
+        static std::mutex pad_mutex;
+        static std::map<std::array<int, 10>, std::pair<int, int>> pad_cache;
+        const std::array<int, 10> key = {a.TH, a.TW, a.G, a.PW, a.PH, a.sh, a.sw, m16 ? 1 : 0, cks, pp.tile};
         int best_p = 0, best_q = 0;
-        const int qmax = (m16 || a.G > 1) ? 32 : 1;
-        for (int q = 0; q < qmax && pad_enabled; ++q)
-            for (int p = 0; p < 32; ++p) {
-                const int PWL = a.PW + p, PS = a.PH * PWL + q;
-                if (patch_lds_bytes(pp.tile, ntaps, a.G, PS) > 64 * 1024) continue;
-                long cost = 0;
-                for (int b = 0; b < blocks; ++b) {
-                    int cnt[32] = {0};
-                    int worst = 0;
-                    for (int l = 0; l < 32; ++l) {
-                        int pix = b * pxw + l % pxw;
-                        const int k = m16 ? l / 16 : 0;
-                        if (pix >= tile_pixels) pix = 0;
-                        const int g = pix / (a.TH * a.TW), rem = pix - g * (a.TH * a.TW);
-                        const int py = rem / a.TW, px = rem - py * a.TW;
-                        const int addr = g * cks * PS + py * a.sh * PWL + px * a.sw + k * PS;
-                        if (++cnt[addr & 31] > worst) worst = cnt[addr & 31];
+        bool cached = false;
+        {
+            std::lock_guard<std::mutex> lock(pad_mutex);
+            auto it = pad_cache.find(key);
+            if (it != pad_cache.end()) { best_p = it->second.first; best_q = it->second.second; cached = true; }
+        }
+        if (!cached && pad_enabled) {
+            long best = -1;
+            const int qmax = (m16 || a.G > 1) ? 32 : 1;
+            for (int q = 0; q < qmax; ++q)
+                for (int p = 0; p < 32; ++p) {
+                    const int PWL = a.PW + p, PS = a.PH * PWL + q;
+                    if (patch_lds_bytes(pp.tile, ntaps, a.G, PS) > 64 * 1024) continue;
+                    long cost = 0;
+                    for (int b = 0; b < blocks; ++b) {
+                        int cnt[32] = {0};
+                        int worst = 0;
+                        for (int l = 0; l < 32; ++l) {
+                            int pix = b * pxw + l % pxw;
+                            const int k = m16 ? l / 16 : 0;
+                            if (pix >= tile_pixels) pix = 0;
+                            const int g = pix / (a.TH * a.TW), rem = pix - g * (a.TH * a.TW);
+                            const int py = rem / a.TW, px = rem - py * a.TW;
+                            const int addr = g * cks * PS + py * a.sh * PWL + px * a.sw + k * PS;
+                            if (++cnt[addr & 31] > worst) worst = cnt[addr & 31];
+                        }
+                        cost += worst;
                     }
-                    cost += worst;
+                    const long score = cost * 100000 + (long)a.G * cks * PS;  // fewest conflicts first, then the smallest patch
+                    if (best < 0 || score < best) { best = score; best_p = p; best_q = q; }
                 }
-                const long score = cost * 100000 + (long)a.G * cks * PS;  // fewest conflicts first, then the smallest patch
-                if (best < 0 || score < best) { best = score; best_p = p; best_q = q; }
-            }
+            std::lock_guard<std::mutex> lock(pad_mutex);
+            pad_cache[key] = {best_p, best_q};
+        }
         a.PWL = a.PW + best_p;
         a.PS = a.PH * a.PWL + best_q;
+
     }
     for (int cls = 0; cls < 4; ++cls) {
         if (L->kind == Layer::DECONV) {

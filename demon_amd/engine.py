@@ -112,7 +112,7 @@ class DemonContext:
         """installs demon_amd/tuned/plan_<H>x<W>_n<n>.json if it exists; returns True when a plan was loaded"""
         import json
         import os
-        directory = directory or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
+        directory = directory or os.environ.get("DEMON_PLAN_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
         tag = "" if self.version == 1 else "v2_"
         path = os.path.join(directory, "plan_%s%dx%d_n%d.json" % (tag, self.H, self.W, int(n)))
         if not os.path.exists(path):
