@@ -557,11 +557,25 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
     Layer::Tuned best_t{0, heur.tile, heur.ksplit};
     for (const Cand &cd : cands) {
         L->tuned[n] = Layer::Tuned{cd.kind, cd.tile, cd.ksplit};
-        run_layer(L, n, c->stream, c->d_ws);  // warm-up
-        hipEventRecord(e0, c->stream);
-        for (int i = 0; i < 3; ++i) run_layer(L, n, c->stream, c->d_ws);
-        hipEventRecord(e1, c->stream);
-        if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) { hipEventDestroy(e0); hipEventDestroy(e1); return DEMON_ERR_HIP; }
+        // timed as a replayed hipGraph of five launches, like the real sequences run: the host-side planning of an eager
+        // launch (tens of microseconds for the small layers) must not leak into the comparison
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            for (int i = 0; i < 5; ++i) run_layer(L, n, c->stream, c->d_ws);
+            ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (ok) {
+            hipGraphLaunch(exec, c->stream);  // warm-up
+            hipEventRecord(e0, c->stream);
+            hipGraphLaunch(exec, c->stream);
+            hipEventRecord(e1, c->stream);
+            ok = hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess;
+        }
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph) hipGraphDestroy(graph);
+        if (!ok) { hipEventDestroy(e0); hipEventDestroy(e1); return DEMON_ERR_HIP; }
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) { best = ms; best_t = Layer::Tuned{cd.kind, cd.tile, cd.ksplit}; }
