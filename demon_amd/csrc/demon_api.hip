@@ -91,6 +91,7 @@ struct demon_ctx {
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> events;  // fork / join events, one per use inside a sequence
     int opt_side_branches = 1;
+    int opt_fused_pairs = 0;  // conv_pair.hip: measured neutral end to end, see docs/experiments
 };
 
 namespace {
@@ -590,6 +591,25 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
     return DEMON_OK;
 }
 
+// k x 1 + 1 x k pair as one launch (conv_pair.hip); false -> the caller runs the two layers one after the other
+bool run_pair(const Layer *Ly, const Layer *Lx, int n, hipStream_t s)
+{
+    PairArgs a;
+    a.in = Ly->in.ptr(); a.out = Lx->out.ptr();
+    a.w1 = Ly->d_wp; a.b1 = Ly->d_bias; a.w2 = Lx->d_wp; a.b2 = Lx->d_bias;
+    a.N = n; a.Cin = Ly->Cin; a.H = Ly->in.H; a.W = Ly->in.W; a.in_n_stride = Ly->in.n_stride();
+    a.CM = Ly->Cout; a.CMk = Lx->Cin; a.CO = Lx->Cout; a.Mpad1 = Ly->Mpad; a.Mpad2 = Lx->Mpad;
+    a.Hm = Ly->out.H; a.Ho = Lx->out.H; a.Wo = Lx->out.W; a.out_n_stride = Lx->out.n_stride();
+    a.ph = Ly->ph; a.pw = Lx->pw;
+    conv_pair_tiles(a.Ho, a.Wo, a.tiles_y, a.tiles_x);
+    const int cks = conv_pair_cks(Ly->kh);
+    a.steps1 = (a.Cin + cks - 1) / cks;
+    a.steps2 = (a.CM + cks - 1) / cks;
+    static const int xcd_order = getenv("DEMON_XCD_ORDER") ? atoi(getenv("DEMON_XCD_ORDER")) : 1;
+    a.xcd = xcd_order;
+    return launch_conv_pair(a, Ly->kh, Ly->sh, s);
+}
+
 // ---- topology builder ---------------------------------------------------------------------------------
 struct Builder {
     demon_ctx *c;
@@ -653,8 +673,33 @@ struct Builder {
         char key[64];
         snprintf(key, sizeof key, "tmp_y_%dx%dx%d", cy, Hmid, in.W);
         View mid = buffer(c, key, cy, Hmid, in.W);
-        make(name + "y", Layer::CONV, in, mid, k, 1, s, 1, 1);
-        make(name + "x", Layer::CONV, mid, out, 1, k, 1, s, 1);
+        // large maps with few channels (levels 1-2): one fused launch for the pair (conv_pair.hip) when the option is on
+        const bool fusable = conv_pair_applies(k, s, in.C, cy, out.C) && (long)out.H * out.W >= 2048;
+        if (!fusable) {
+            make(name + "y", Layer::CONV, in, mid, k, 1, s, 1, 1);
+            make(name + "x", Layer::CONV, mid, out, 1, k, 1, s, 1);
+            return;
+        }
+        const int jn = join_next;  // the pair is ONE step: its join flag must not be consumed by the first make()
+        Layer *Ly = make(name + "y", Layer::CONV, in, mid, k, 1, s, 1, 1, nullptr, false);
+        Layer *Lx = make(name + "x", Layer::CONV, mid, out, 1, k, 1, s, 1, nullptr, false);
+        join_next = jn;
+        Step st;
+        st.name = Ly->name + "+x";
+        st.kernel = "conv_mfma";
+        st.flops_per_sample = 2.0 * Ly->Cout * Ly->K * Ly->out.H * Ly->out.W + 2.0 * Lx->Cout * Lx->K * Lx->out.H * Lx->out.W;
+        st.bytes_per_sample = 4.0 * ((double)in.C * in.H * in.W + (double)out.C * out.H * out.W);
+        st.bytes_fixed = 4.0 * ((double)Ly->K * Ly->Cout + (double)Lx->K * Lx->Cout + Ly->Cout + Lx->Cout);
+        demon_ctx *cc = c;
+        float *ws = side ? c->d_ws_side : c->d_ws;
+        st.fn = [cc, Ly, Lx, ws](int n, hipStream_t s2) {
+            if (cc->opt_fused_pairs && run_pair(Ly, Lx, n, s2)) return;
+            run_layer(Ly, n, s2, ws);
+            run_layer(Lx, n, s2, ws);
+        };
+        st.image_only = tag;
+        stamp(st);
+        steps->push_back(st);
     }
     // blocks_original.py:97-110 (lrelu) and :64-75 (linear)
     Layer *deconv(const std::string &name, View in, View out, int act) { return make(name, Layer::DECONV, in, out, 4, 4, 2, 2, act); }
@@ -996,7 +1041,8 @@ int run_sequence(demon_ctx *c, int kind, int n, int iterations)
         return DEMON_OK;
     }
     char key[64];
-    snprintf(key, sizeof key, "%d:%d:%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method, c->opt_reuse_image, c->opt_side_branches);
+    snprintf(key, sizeof key, "%d:%d:%d:%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method, c->opt_reuse_image, c->opt_side_branches,
+             c->opt_fused_pairs);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -1089,6 +1135,7 @@ static int create_impl(demon_ctx **out, int device, int max_batch, int height, i
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, DEMON_ERR_HIP, "hipSetDevice failed");
     std::unique_ptr<demon_ctx> c(new demon_ctx);
     c->device = device; c->max_batch = max_batch; c->H = height; c->W = width; c->variant = variant;
+    if (const char *fp = getenv("DEMON_FUSED_PAIRS")) c->opt_fused_pairs = atoi(fp) ? 1 : 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
         return fail(nullptr, DEMON_ERR_HIP, "hipStreamCreate failed");
     demon_ctx *p = c.get();
@@ -1245,6 +1292,7 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
         return DEMON_OK;
     }
     if (!strcmp(key, "reuse_image_features")) { c->opt_reuse_image = value ? 1 : 0; return DEMON_OK; }
+    if (!strcmp(key, "fused_pairs")) { c->opt_fused_pairs = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "side_branches")) { c->opt_side_branches = (value && c->side_stream && c->d_ws_side != c->d_ws) ? 1 : 0; return DEMON_OK; }
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }

@@ -124,6 +124,28 @@ int patch_tile_threads(int tile);
 size_t patch_lds_bytes(int tile, int ntaps, int G, int PS);
 void launch_conv_patch(const PatchArgs &a, int tile, int ntaps, int nclasses, hipStream_t stream);
 
+// ---- fused separable pair (conv_pair.hip): k x 1 conv + leaky relu + 1 x k conv + leaky relu in one launch ----------------------
+struct PairArgs {
+    const float *in;
+    float *out;
+    const float *w1, *b1;  // k x 1 layer: packed weights [tap*Cin + ci][Mpad1], bias [Mpad1]
+    const float *w2, *b2;  // 1 x k layer: packed weights [tap*CMk + cm][Mpad2], bias [Mpad2]
+    int N, Cin, H, W;
+    long in_n_stride;
+    int CM, CMk, CO, Mpad1, Mpad2;  // intermediate / output channels (CMk = CM: reduction channels of the second layer)
+    int Hm;                // rows of the intermediate (its width is W)
+    int Ho, Wo;
+    long out_n_stride;
+    int ph, pw;            // zeros in front of the first row (k x 1 layer) / column (1 x k layer)
+    int tiles_y, tiles_x;
+    int steps1, steps2;    // K-steps of the two phases
+    int xcd;
+};
+bool conv_pair_applies(int k, int stride, int cin, int cm, int co);
+void conv_pair_tiles(int Ho, int Wo, int &tiles_y, int &tiles_x);
+int conv_pair_cks(int k);
+bool launch_conv_pair(const PairArgs &a, int k, int stride, hipStream_t s);
+
 // ---- tiny heads (conv_small.hip): VALU direct conv for Cout <= 4, fused motion tail -------------------------------------
 struct SmallConvArgs {
     const float *in;

@@ -9,6 +9,7 @@ from conftest import rel_l1, make_inputs
 from oracle import net_ref
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-3
 KEYS = ("predict_flow5", "predict_flow2", "predict_depth2", "predict_normal2", "predict_rotation", "predict_translation")
 
@@ -266,3 +267,45 @@ def test_two_context_pipeline_matches_single_context(gpu_ctx, synth_weights):
             np.testing.assert_array_equal(got[k][4 * i:4 * i + 4], want[k], err_msg=k)
     for k in got:
         np.testing.assert_array_equal(got[k], again[k])
+
+
+def test_fused_pairs_option_matches(gpu_ctx, ref):
+    """opt-in fused k x 1 / 1 x k pairs (conv_pair.hip: conv1 and the extra-input pairs as one launch each, intermediate in LDS):
+    same arithmetic in another summation order -> oracle parity holds and the default path agrees to 1e-5"""
+    pair, img2_2 = make_inputs(3, seed=17)
+    base = gpu_ctx.full(pair, img2_2, iterations=2)
+    gpu_ctx.set_option("fused_pairs", 1)
+    try:
+        fused = gpu_ctx.full(pair, img2_2, iterations=2)
+    finally:
+        gpu_ctx.set_option("fused_pairs", 0)
+    _cmp(fused, ref.full(pair, img2_2, iterations=2), KEYS + ("predict_depth0",))
+    for k in KEYS + ("predict_depth0",):
+        assert rel_l1(fused[k], base[k]) < 1e-5, k
+    assert any(not np.array_equal(fused[k], base[k]) for k in KEYS)   # the option really switched kernels
+
+
+def test_fused_pairs_all_types_in_subprocess(tmp_path):
+    """every instantiation of the fused pair kernel (9 / 7 / 3 taps, 32 and 64 channels; DEMON_FUSED_PAIRS_ALL is read once per
+    process) against the default path, for the original and the v2 model"""
+    import subprocess
+    import sys
+    script = tmp_path / "fused_all.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import make_inputs, rel_l1\n"
+        "from demon_amd import DemonContext, weights\n"
+        "for version in (1, 2):\n"
+        "    ctx = DemonContext(0, 2, version=version); ctx.set_weights(weights.synthetic_weights(1, version=version))\n"
+        "    pair, img = make_inputs(2, seed=18)\n"
+        "    base = ctx.full(pair, img, 2)\n"
+        "    ctx.set_option('fused_pairs', 1)\n"
+        "    fused = ctx.full(pair, img, 2)\n"
+        "    for k in base:\n"
+        "        assert np.isfinite(fused[k]).all() and rel_l1(fused[k], base[k]) < 1e-5, (version, k, rel_l1(fused[k], base[k]))\n"
+        "    ctx.close()\n"
+        "print('fused ok')\n" % (ROOT_DIR, os.path.join(ROOT_DIR, "tests")))
+    env = dict(os.environ, DEMON_FUSED_PAIRS_ALL="1")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fused ok" in out.stdout, out.stdout + out.stderr
