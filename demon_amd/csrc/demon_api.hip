@@ -52,6 +52,9 @@ struct Step {
     // iterative nets only: 1 = conv1 / conv2 (depend on image_pair and weights only, identical in every iteration);
     // 2 = copy of the cached conv2 output into the concat buffer (runs instead of them when the option is on)
     int image_only = 0;
+    // k x 1 / 1 x k pairs that conv_pair.hip can run as one launch exist twice in the list: pair = 1 is the fused step (runs when
+    // option fused_pairs is on), pair = 2 marks the two ordinary layer steps (run when it is off)
+    int pair = 0;
     // Side branch: small kernel chains that do not depend on the steps that follow them on the main stream (the motion head next
     // to the decoder of the depth+motion block, predict_flow5 -> upsample next to refine4 of the flow block) run on a second
     // stream.  side = 1 marks them; fork = 1 on the first one (side stream waits for everything enqueued so far on the main
@@ -680,26 +683,41 @@ struct Builder {
             make(name + "x", Layer::CONV, mid, out, 1, k, 1, s, 1);
             return;
         }
-        const int jn = join_next;  // the pair is ONE step: its join flag must not be consumed by the first make()
+        // both forms go into the list (Step::pair): the fused step first, then the two layers
+        const int jn = join_next, fk = fork_next;
         Layer *Ly = make(name + "y", Layer::CONV, in, mid, k, 1, s, 1, 1, nullptr, false);
         Layer *Lx = make(name + "x", Layer::CONV, mid, out, 1, k, 1, s, 1, nullptr, false);
-        join_next = jn;
         Step st;
         st.name = Ly->name + "+x";
         st.kernel = "conv_mfma";
         st.flops_per_sample = 2.0 * Ly->Cout * Ly->K * Ly->out.H * Ly->out.W + 2.0 * Lx->Cout * Lx->K * Lx->out.H * Lx->out.W;
         st.bytes_per_sample = 4.0 * ((double)in.C * in.H * in.W + (double)out.C * out.H * out.W);
         st.bytes_fixed = 4.0 * ((double)Ly->K * Ly->Cout + (double)Lx->K * Lx->Cout + Ly->Cout + Lx->Cout);
-        demon_ctx *cc = c;
         float *ws = side ? c->d_ws_side : c->d_ws;
-        st.fn = [cc, Ly, Lx, ws](int n, hipStream_t s2) {
-            if (cc->opt_fused_pairs && run_pair(Ly, Lx, n, s2)) return;
+        st.fn = [Ly, Lx, ws](int n, hipStream_t s2) {
+            if (run_pair(Ly, Lx, n, s2)) return;
             run_layer(Ly, n, s2, ws);
             run_layer(Lx, n, s2, ws);
         };
         st.image_only = tag;
+        st.pair = 1;
+        join_next = jn; fork_next = fk;
         stamp(st);
         steps->push_back(st);
+        for (Layer *L : {Ly, Lx}) {
+            Step sl;
+            sl.name = L->name;
+            sl.kernel = "conv_mfma";
+            sl.flops_per_sample = 2.0 * L->Cout * L->K * L->out.H * L->out.W;
+            sl.bytes_per_sample = 4.0 * ((double)L->in.C * L->in.H * L->in.W + (double)L->out.C * L->out.H * L->out.W);
+            sl.bytes_fixed = 4.0 * ((double)L->K * L->Cout + L->Cout);
+            sl.fn = [L, ws](int n, hipStream_t s2) { run_layer(L, n, s2, ws); };
+            sl.image_only = tag;
+            sl.pair = 2;
+            if (L == Ly) { join_next = jn; fork_next = fk; }  // the same fork / join as the fused form
+            stamp(sl);
+            steps->push_back(sl);
+        }
     }
     // blocks_original.py:97-110 (lrelu) and :64-75 (linear)
     Layer *deconv(const std::string &name, View in, View out, int act) { return make(name, Layer::DECONV, in, out, 4, 4, 2, 2, act); }
@@ -998,6 +1016,7 @@ void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t 
         if (st.image_only == 1 && mode == 2) continue;
         if (st.image_only == 2 && mode != 2) continue;
         if (st.image_only == 3 && mode != 1) continue;
+        if ((st.pair == 1 && !c->opt_fused_pairs) || (st.pair == 2 && c->opt_fused_pairs)) continue;
         if (!branches) { st.fn(n, s); continue; }
         if (st.fork && ev < c->events.size()) {
             hipEventRecord(c->events[ev], s);
@@ -1507,7 +1526,7 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
     for (auto &s : c->net_boot) seq.push_back(&s);
     for (int i = 0; i < iterations; ++i)
         for (auto &s : c->net_iter)
-            if (s.image_only < 2) seq.push_back(&s);
+            if (s.image_only < 2 && !((s.pair == 1 && !c->opt_fused_pairs) || (s.pair == 2 && c->opt_fused_pairs))) seq.push_back(&s);
     for (auto &s : c->net_refine) seq.push_back(&s);
     std::vector<hipEvent_t> ev(2 * seq.size());
     for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
