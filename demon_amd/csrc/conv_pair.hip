@@ -38,7 +38,12 @@ struct PairGeom {
     static constexpr int MS = N1;                         // mid plane stride
     static constexpr int MID = MB1 * 32 * MS;
     static constexpr int STAGE1 = 2 * (KD1 * MB1 * 32 + PELEMS);
-    static constexpr int STAGE2 = 2 * KD2 * MB2 * 32;
+    // phase-2 weights: the whole [K * CM][BM2] matrix stays in LDS when it is at most 40 KB (no K-steps, no barriers in phase 2);
+    // otherwise tiles of CKS2 channels stream through a double buffer
+    static constexpr int W2ALL = K * MB1 * 32 * MB2 * 32;
+    static constexpr bool W2RES = W2ALL * 4 <= 40 * 1024;
+    static constexpr int W2CH = W2ALL / 4, W2PER = (W2CH + 255) / 256;
+    static constexpr int STAGE2 = W2RES ? W2ALL : 2 * KD2 * MB2 * 32;
     static constexpr int STAGE = STAGE1 > STAGE2 ? STAGE1 : STAGE2;
     static constexpr size_t lds_bytes = sizeof(float) * (size_t)(MID + STAGE);
 };
@@ -161,13 +166,24 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
         __syncthreads();
     }
 
-    // ---- phase 2 weights: first tile in flight while the intermediate goes to LDS
+    // ---- phase 2 weights
+    constexpr bool W2RES = G::W2RES;
+    constexpr int W2PER = G::W2PER;
+    floatx4 wreg[W2RES ? W2PER : 1];
     int a2off[A2PER];
+    const int w2count = K * a.CMk * (BM2 / 4);  // float4 chunks of the real matrix (rows tap*CM + cm, BM2 == Mpad2 floats each)
+    if (W2RES) {
+        // resident: every thread fetches its chunks now (they fly during the intermediate's epilogue) ...
 #pragma unroll
-    for (int i = 0; i < A2PER; ++i) {
-        const int q = tid + i * 256;
-        const int r = q / (BM2 / 4), c4 = q - r * (BM2 / 4);
-        a2off[i] = ((r / CKS2) * a.CMk + (r % CKS2)) * a.Mpad2 + c4 * 4;
+        for (int i = 0; i < W2PER; ++i)
+            if (tid + i * 256 < w2count) wreg[i] = *reinterpret_cast<const floatx4 *>(a.w2 + (long)(tid + i * 256) * 4);
+    } else {
+#pragma unroll
+        for (int i = 0; i < A2PER; ++i) {
+            const int q = tid + i * 256;
+            const int r = q / (BM2 / 4), c4 = q - r * (BM2 / 4);
+            a2off[i] = ((r / CKS2) * a.CMk + (r % CKS2)) * a.Mpad2 + c4 * 4;
+        }
     }
     auto load2 = [&](int step) {
         const float *__restrict__ ab = a.w2 + (long)step * CKS2 * a.Mpad2;
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
         for (int i = 0; i < A2PER; ++i)
             if (tid + i * 256 < G::A2CH) *reinterpret_cast<floatx4 *>(A + (tid + i * 256) * 4) = areg[i];
     };
-    load2(0);
+    if (!W2RES) load2(0);
 
     // ---- intermediate: bias, leaky relu, zero outside the image (the 1 x k conv's padding), -> mid
 #pragma unroll
@@ -202,7 +218,14 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
                 }
         }
     }
-    store2(0);   // the phase-1 staging buffers are free: every wave passed the barrier that ended the last K-step
+    // the phase-1 staging buffers are free: every wave passed the barrier that ended the last K-step
+    if (W2RES) {
+#pragma unroll
+        for (int i = 0; i < W2PER; ++i)
+            if (tid + i * 256 < w2count) *reinterpret_cast<floatx4 *>(stage + (tid + i * 256) * 4) = wreg[i];
+    } else {
+        store2(0);
+    }
     __syncthreads();
 
     // ---- phase 2: wave = output row `wave` of the tile, lane = column
@@ -212,20 +235,44 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[i][r] = 0.0f;
     const int mbase = 4 * (wave * TWp + l31 * S + lhi * MS);
-    for (int s = 0; s < a.steps2; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < a.steps2) load2(s + 1);
-        const char *Mb = reinterpret_cast<const char *>(mid + (long)s * CKS2 * MS) + mbase;
-        const float *A = As2 + buf * (KD2 * BM2);
+    if (W2RES) {
+        // tap major, channel pairs inside: k2 = tap*CM + cm, no barrier until the end
+        const char *Mb = reinterpret_cast<const char *>(mid) + mbase;
+        const float *A = stage + l31;
+        for (int b = 0; b < K; ++b) {
+            const float *Ab = A + (long)(b * a.CMk + lhi) * BM2;
+            const char *Mt = Mb + 4 * b;
+            for (int cm0 = 0; cm0 < a.CMk; cm0 += 8) {  // CM is a multiple of 8 (conv_pair_applies)
+                float av[4][MB2], bv[4];
 #pragma unroll
-        for (int kk = 0; kk < KD2 / 2; ++kk) {
-            const int k = 2 * kk + lhi;
-            const float bv = *reinterpret_cast<const float *>(Mb + 4 * (((2 * kk) % CKS2) * MS + (2 * kk) / CKS2));
+                for (int u = 0; u < 4; ++u) {
+                    const int cm = cm0 + 2 * u;
+                    bv[u] = *reinterpret_cast<const float *>(Mt + 4 * cm * MS);
 #pragma unroll
-            for (int i = 0; i < MB2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k * BM2 + i * 32 + l31], bv, acc2[i], 0, 0, 0);
+                    for (int i = 0; i < MB2; ++i) av[u][i] = Ab[cm * BM2 + i * 32];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < MB2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u], acc2[i], 0, 0, 0);
+            }
         }
-        if (s + 1 < a.steps2) store2(buf ^ 1);
-        __syncthreads();
+    } else {
+        for (int s = 0; s < a.steps2; ++s) {
+            const int buf = s & 1;
+            if (s + 1 < a.steps2) load2(s + 1);
+            const char *Mb = reinterpret_cast<const char *>(mid + (long)s * CKS2 * MS) + mbase;
+            const float *A = As2 + buf * (KD2 * BM2);
+#pragma unroll
+            for (int kk = 0; kk < KD2 / 2; ++kk) {
+                const int k = 2 * kk + lhi;
+                const float bv = *reinterpret_cast<const float *>(Mb + 4 * (((2 * kk) % CKS2) * MS + (2 * kk) / CKS2));
+#pragma unroll
+                for (int i = 0; i < MB2; ++i) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[k * BM2 + i * 32 + l31], bv, acc2[i], 0, 0, 0);
+            }
+            if (s + 1 < a.steps2) store2(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- output
@@ -264,15 +311,17 @@ static bool launch_pair_t(const PairArgs &a, hipStream_t s)
 }
 
 // Which pairs the fused kernel serves.  It exists for taps / stride (9,2), (7,2), (3,1) and up to 64 channels on both sides, and is
-// ENABLED where it measured faster than the two launches (batch 32, 256x192): conv1 (6 -> 32 -> 32, 9 taps: 0.156 -> 0.142 ms) and
-// the extra-input pairs (7..9 -> 32 -> 32, 3 taps: 0.029 -> 0.023 ms).  With 32+ input channels the first phase dominates and its
-// 9 (or 5) pixel blocks do not split evenly over the 4 waves: conv2 0.070 -> 0.084 ms, conv2_1 0.072 -> 0.088 ms.
+// USED where it measured faster end to end (batch 32, 256x192): conv1 (6 -> 32 -> 32, 9 taps; 0.156 -> 0.142 ms per pair, +0.6 %
+// overall, and its 100 MB intermediate never reaches HBM).  The extra-input pairs (7..9 -> 32 -> 32, 3 taps) are faster fused
+// (0.029 -> 0.023 ms) but already hidden on the side stream; with 32+ input channels the first phase dominates and its 9 (or 5)
+// pixel blocks do not split evenly over the 4 waves (conv2 0.070 -> 0.084 ms, conv2_1 0.072 -> 0.088 ms).
+// DEMON_FUSED_PAIRS_ALL=1 turns every supported pair on (tests, experiments).
 bool conv_pair_applies(int k, int stride, int cin, int cm, int co)
 {
-    static const int all = getenv("DEMON_FUSED_PAIRS_ALL") ? atoi(getenv("DEMON_FUSED_PAIRS_ALL")) : 0;  // experiment hook
+    static const int all = getenv("DEMON_FUSED_PAIRS_ALL") ? atoi(getenv("DEMON_FUSED_PAIRS_ALL")) : 0;
     const bool shape = (k == 9 && stride == 2) || (k == 7 && stride == 2) || (k == 3 && stride == 1);
     if (!shape || cm > 64 || co > 64 || cm % 8) return false;
-    return all || cin <= 16;
+    return all || (k == 9 && cin <= 16);
 }
 
 void conv_pair_tiles(int Ho, int Wo, int &tiles_y, int &tiles_x)

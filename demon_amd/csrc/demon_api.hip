@@ -94,7 +94,7 @@ struct demon_ctx {
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> events;  // fork / join events, one per use inside a sequence
     int opt_side_branches = 1;
-    int opt_fused_pairs = 0;  // conv_pair.hip: measured neutral end to end, see docs/experiments
+    int opt_fused_pairs = 1;  // conv_pair.hip for the pairs conv_pair_applies() selects
 };
 
 namespace {

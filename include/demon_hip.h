@@ -83,8 +83,8 @@ int demon_set_weights_blob_device(demon_ctx *ctx, const void *device_blob, int64
  * depend on the images only) once per forward pass instead of once per iteration -- same results, 16 launches fewer;
  * "side_branches" 0/1 (default 1): the motion head and the level-5 flow head run on a second HIP stream next to the decoder
  * they do not depend on (fork / join by events, captured into the same hipGraph) -- same kernels, same results;
- * "fused_pairs" 0/1 (default 0): the k x 1 / 1 x k pairs with few input channels on the large maps (conv1, conv2_extra_inputs) as
- * one launch each, the intermediate staying in LDS (conv_pair.hip) -- same arithmetic, other summation order */
+ * "fused_pairs" 0/1 (default 1): the first k x 1 / 1 x k pair (conv1, 6 input channels, the largest intermediate) as one launch,
+ * the intermediate staying in LDS (conv_pair.hip) -- same arithmetic, other summation order */
 int demon_set_option(demon_ctx *ctx, const char *key, int value);
 /* Times every applicable kernel variant (im2col / patch-staged, tile shape, split-K) of every layer at batch n on
  * this GPU and keeps the fastest per layer (~1 s; results do not change, only launch plans). */

@@ -270,15 +270,15 @@ def test_two_context_pipeline_matches_single_context(gpu_ctx, synth_weights):
 
 
 def test_fused_pairs_option_matches(gpu_ctx, ref):
-    """opt-in fused k x 1 / 1 x k pairs (conv_pair.hip: conv1 and the extra-input pairs as one launch each, intermediate in LDS):
-    same arithmetic in another summation order -> oracle parity holds and the default path agrees to 1e-5"""
+    """fused k x 1 / 1 x k pair (conv_pair.hip: conv1 as one launch, intermediate in LDS) vs the two separate launches:
+    same arithmetic in another summation order -> oracle parity holds and the two paths agree to 1e-5"""
     pair, img2_2 = make_inputs(3, seed=17)
-    base = gpu_ctx.full(pair, img2_2, iterations=2)
-    gpu_ctx.set_option("fused_pairs", 1)
+    fused = gpu_ctx.full(pair, img2_2, iterations=2)   # default: on
+    gpu_ctx.set_option("fused_pairs", 0)
     try:
-        fused = gpu_ctx.full(pair, img2_2, iterations=2)
+        base = gpu_ctx.full(pair, img2_2, iterations=2)
     finally:
-        gpu_ctx.set_option("fused_pairs", 0)
+        gpu_ctx.set_option("fused_pairs", 1)
     _cmp(fused, ref.full(pair, img2_2, iterations=2), KEYS + ("predict_depth0",))
     for k in KEYS + ("predict_depth0",):
         assert rel_l1(fused[k], base[k]) < 1e-5, k
@@ -299,9 +299,9 @@ def test_fused_pairs_all_types_in_subprocess(tmp_path):
         "for version in (1, 2):\n"
         "    ctx = DemonContext(0, 2, version=version); ctx.set_weights(weights.synthetic_weights(1, version=version))\n"
         "    pair, img = make_inputs(2, seed=18)\n"
-        "    base = ctx.full(pair, img, 2)\n"
-        "    ctx.set_option('fused_pairs', 1)\n"
         "    fused = ctx.full(pair, img, 2)\n"
+        "    ctx.set_option('fused_pairs', 0)\n"
+        "    base = ctx.full(pair, img, 2)\n"
         "    for k in base:\n"
         "        assert np.isfinite(fused[k]).all() and rel_l1(fused[k], base[k]) < 1e-5, (version, k, rel_l1(fused[k], base[k]))\n"
         "    ctx.close()\n"
