@@ -19,7 +19,7 @@ def load(d):
     with open(os.path.join(d, "p_counter_collection.csv")) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
-            fam = "conv" if ("conv_mfma_kernel" in name or "conv_patch_kernel" in name) else name.split("(")[0].replace("demon::", "")
+            fam = "conv" if any(k in name for k in ("conv_mfma_kernel", "conv_patch_kernel", "deconv4_kernel", "conv_pair_kernel")) else name.split("(")[0].replace("demon::", "")
             agg[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
