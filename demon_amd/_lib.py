@@ -71,6 +71,7 @@ SIGNATURES = {
     "demon_op_replace_nonfinite": (_I, [_P, c_float_p, c_float_p, ctypes.c_int64, _F]),
     "demon_op_scale_invariant_gradient": (_I, [_P, c_float_p, c_float_p, _I, _I, _I, c_int_p, c_float_p, _I, _F]),
     "demon_op_median3x3_downsample": (_I, [_P, c_float_p, c_float_p, _I, _I, _I]),
+    "demon_op_pointwise_l2_loss": (_I, [_P, c_float_p, c_float_p, c_float_p, _I, _I, _I, _I, ctypes.c_float]),
     "demon_op_conv2d": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 12),
     "demon_op_deconv4x4s2": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 6),
     "demon_op_dense": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 4),

@@ -1656,6 +1656,24 @@ int demon_op_median3x3_downsample(demon_ctx *c, float *out, const float *in, int
     OP_FINISH(c, d_out, out, nc * ho * wo);
 }
 
+int demon_op_pointwise_l2_loss(demon_ctx *c, float *loss, const float *inp, const float *gt, int n, int ch, int h, int w, float epsilon)
+{
+    OP_PROLOGUE(c);
+    if (!loss || !inp || !gt || n < 1 || ch < 1 || h < 1 || w < 1) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    const size_t count = (size_t)n * ch * h * w, blocks = ((size_t)n * h * w + 255) / 256;
+    float *d_inp = tmp.upload(inp, count), *d_gt = tmp.upload(gt, count), *d_part = tmp.alloc(blocks);
+    if (!d_inp || !d_gt || !d_part) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    launch_pointwise_l2_partial(d_part, d_inp, d_gt, n, ch, h * w, epsilon, c->stream);
+    std::vector<float> part(blocks);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(part.data(), d_part, sizeof(float) * blocks, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double sum = 0.0;
+    for (float v : part) sum += v;
+    *loss = (float)(sum / ((double)n * h * w));
+    return DEMON_OK;
+}
+
 // one stand-alone contraction layer through the same packing + kernel path the networks use
 static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const float *in, const float *w, const float *bias,
                             int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw, int lrelu, bool same = false)

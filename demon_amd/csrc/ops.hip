@@ -536,6 +536,39 @@ void launch_sig(float *out, const float *in, int NC, int H, int W, const int *de
     hipLaunchKernelGGL(sig_kernel, grid, dim3(256), 0, s, out, in, H, W, sp, eps, halo);
 }
 
+// pointwise_l2_loss (v2/losses.py:33-54): mean over (n, y, x) of sqrt(sum_c replace_nonfinite(inp - gt)^2 + epsilon).
+// grid: ceil(N*H*W / 256) blocks; every block writes the sum of its 256 pixels to partial[blockIdx.x]
+// (wave shuffle + LDS reduction); the host adds the few hundred partials in double.
+__global__ __launch_bounds__(256) void pointwise_l2_partial_kernel(float *__restrict__ partial, const float *__restrict__ inp,
+                                                                   const float *__restrict__ gt, int N, int C, int HW, float epsilon)
+{
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.0f;
+    if (p < (long)N * HW) {
+        const int n = (int)(p / HW), idx = (int)(p - (long)n * HW);
+        const long base = (long)n * C * HW + idx;
+        float s = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            float d = inp[base + (long)c * HW] - gt[base + (long)c * HW];
+            if (!isfinite(d)) d = 0.0f;  // sops.replace_nonfinite(inp - gt), value 0
+            s = fmaf(d, d, s);
+        }
+        v = sqrtf(s + epsilon);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+void launch_pointwise_l2_partial(float *partial, const float *inp, const float *gt, int N, int C, int HW, float epsilon, hipStream_t s)
+{
+    const long P = (long)N * HW;
+    hipLaunchKernelGGL(pointwise_l2_partial_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, partial, inp, gt, N, C, HW, epsilon);
+}
+
 void launch_median3x3_downsample(float *out, const float *in, int NC, int H, int W, hipStream_t s)
 {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;

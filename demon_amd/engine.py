@@ -287,6 +287,15 @@ class DemonContext:
         self._check(self.lib.demon_op_median3x3_downsample(self.h, _fp(out), _fp(x), n * c, h, w))
         return out
 
+    def pointwise_l2_loss(self, inp, gt, epsilon):
+        """v2/losses.py:33-54 (NCHW): mean over pixels of sqrt(sum_c replace_nonfinite(inp - gt)^2 + epsilon)"""
+        inp = _f32(inp)
+        gt = _f32(gt, inp.shape, "gt")
+        n, c, h, w = inp.shape
+        out = ctypes.c_float()
+        self._check(self.lib.demon_op_pointwise_l2_loss(self.h, ctypes.byref(out), _fp(inp), _fp(gt), n, c, h, w, float(epsilon)))
+        return float(out.value)
+
     # ---- single layers (TF weight layouts) ----------------------------------------------------------------
     def conv2d(self, x, w_hwio, bias, stride=(1, 1), lrelu=False, padding="caffe"):
         """padding 'caffe': k//2 zeros on both sides then VALID (helpers.py:70-94); 'same': tf.layers.conv2d(padding='same')

@@ -163,6 +163,9 @@ int demon_op_replace_nonfinite(demon_ctx *ctx, float *out, const float *in, int6
 int demon_op_scale_invariant_gradient(demon_ctx *ctx, float *out, const float *in, int nc, int h, int w,
                                       const int *deltas, const float *weights, int ndeltas, float epsilon);
 int demon_op_median3x3_downsample(demon_ctx *ctx, float *out, const float *in, int nc, int h, int w);
+/* pointwise_l2_loss of v2/losses.py:33-54 (NCHW): mean over pixels of sqrt(sum_c replace_nonfinite(inp - gt)^2 + epsilon) */
+int demon_op_pointwise_l2_loss(demon_ctx *ctx, float *loss, const float *inp, const float *gt, int n, int c, int h, int w,
+                               float epsilon);
 
 /* ---- layer-level entry points (host buffers; TF weight layouts) -------------------------------------
  * Replace the tf.layers calls of helpers.py:85-94 / :128-153 (conv2d on a zero padded input),

@@ -170,3 +170,12 @@ def resize_nearest(x, Ho, Wo):
     out = np.empty((N, C, Ho, Wo), np.float32)
     lib().ref_resize_nearest(out.ctypes.data_as(_f32p), px, N * C, H, W, Ho, Wo)
     return out
+
+
+def pointwise_l2_loss(inp, gt, epsilon):
+    """python/depthmotionnet/v2/losses.py:33-54 (NCHW): diff = replace_nonfinite(inp - gt);
+    reduce_mean(sqrt(reduce_sum(diff**2, axis=1) + epsilon)).  numpy, float64 accumulation."""
+    with np.errstate(invalid="ignore"):
+        d = np.asarray(inp, np.float32) - np.asarray(gt, np.float32)
+    d = np.where(np.isfinite(d), d, np.float32(0)).astype(np.float64)
+    return float(np.sqrt((d * d).sum(axis=1) + epsilon).mean())

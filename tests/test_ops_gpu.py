@@ -179,3 +179,17 @@ print("ok")
     env = dict(os.environ, DEMON_WARP_LDS="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 48, 64), (3, 1, 17, 33), (1, 3, 192, 256)])
+def test_pointwise_l2_loss(gpu_ctx, shape):
+    """HIP pointwise_l2_loss (v2/losses.py:33-54) == the numpy restatement, with NaN / inf pixels in prediction and ground truth"""
+    rng = np.random.default_rng(50)
+    inp = rng.standard_normal(shape).astype(np.float32)
+    gt = rng.standard_normal(shape).astype(np.float32)
+    gt.reshape(-1)[::13] = np.nan
+    inp.reshape(-1)[::101] = np.inf
+    for eps in (0.0, 1e-3):
+        got = gpu_ctx.pointwise_l2_loss(inp, gt, eps)
+        want = ops_ref.pointwise_l2_loss(inp, gt, eps)
+        assert abs(got - want) <= 1e-5 * abs(want), (got, want)

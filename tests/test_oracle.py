@@ -301,3 +301,14 @@ def test_v2_variable_table_and_oracle_forward():
     assert r["predict_depth0"].shape == (1, 1, h, w) and r["predict_normal0"].shape == (1, 3, h, w)
     assert r["predict_flow5"].shape == (1, 2, h // 32, w // 32) and r["predict_depth2"].shape == (1, 1, h // 4, w // 4)
     assert all(np.isfinite(v).all() for v in r.values())
+
+
+def test_pointwise_l2_loss_known_answers():
+    """v2/losses.py:33-54: non-finite differences count as zero, epsilon sits under the root, mean over pixels"""
+    inp = np.zeros((1, 2, 1, 3), np.float32)
+    gt = np.zeros((1, 2, 1, 3), np.float32)
+    inp[0, :, 0, 0] = (3.0, 4.0)          # |diff| = 5
+    gt[0, 0, 0, 1] = np.nan               # diff nan -> 0 ; other channel 0 -> sqrt(eps)
+    inp[0, 1, 0, 2] = np.inf              # diff inf -> 0
+    np.testing.assert_allclose(ops_ref.pointwise_l2_loss(inp, gt, 0.0), 5.0 / 3.0)
+    np.testing.assert_allclose(ops_ref.pointwise_l2_loss(inp, gt, 1e-2), (np.sqrt(25.01) + 0.1 + 0.1) / 3.0)
