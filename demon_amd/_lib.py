@@ -32,6 +32,7 @@ _F = ctypes.c_float
 SIGNATURES = {
     "demon_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "demon_create_v2": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
+    "demon_create_ops": (_I, [ctypes.POINTER(_P), _I]),
     "demon_variant": (_I, [_P]),
     "demon_destroy": (_I, [_P]),
     "demon_last_error": (ctypes.c_char_p, [_P]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "demon_op_replace_nonfinite": (_I, [_P, c_float_p, c_float_p, ctypes.c_int64, _F]),
     "demon_op_scale_invariant_gradient": (_I, [_P, c_float_p, c_float_p, _I, _I, _I, c_int_p, c_float_p, _I, _F]),
     "demon_op_median3x3_downsample": (_I, [_P, c_float_p, c_float_p, _I, _I, _I]),
+    "demon_op_depth_to_normals": (_I, [_P, c_float_p, c_float_p, c_float_p, _I, _I, _I, _I]),
     "demon_op_pointwise_l2_loss": (_I, [_P, c_float_p, c_float_p, c_float_p, _I, _I, _I, _I, ctypes.c_float]),
     "demon_op_conv2d": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 12),
     "demon_op_deconv4x4s2": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 6),

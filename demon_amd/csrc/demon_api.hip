@@ -1217,6 +1217,29 @@ int demon_create_v2(demon_ctx **out, int device, int max_batch, int height, int 
     return create_impl(out, device, max_batch, height, width, 2);
 }
 
+int demon_create_ops(demon_ctx **out, int device)
+{
+    if (!out) return fail(nullptr, DEMON_ERR_INVALID, "null ctx pointer");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, DEMON_ERR_HIP, "no HIP device visible (libdemon_hip.so needs an MI355X / gfx950 GPU)");
+    if (device < 0 || device >= ndev) return fail(nullptr, DEMON_ERR_INVALID, "device index out of range");
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, DEMON_ERR_HIP, "hipSetDevice failed");
+    std::unique_ptr<demon_ctx> c(new demon_ctx);
+    c->device = device; c->max_batch = 0; c->variant = 0; c->opt_side_branches = 0;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        return fail(nullptr, DEMON_ERR_HIP, "hipStreamCreate failed");
+    c->d_ws = dev_alloc(c.get(), sizeof(float) * kSplitKWorkspaceFloats);
+    c->d_ws_side = c->d_ws;
+    if (!c->d_ws) {
+        demon_destroy(c.release());
+        return fail(nullptr, DEMON_ERR_HIP, "device allocation failed");
+    }
+    *out = c.release();
+    return DEMON_OK;
+}
+
 int demon_variant(const demon_ctx *c) { return c ? c->variant : 0; }
 
 int demon_destroy(demon_ctx *c)
@@ -1639,10 +1662,22 @@ int demon_op_scale_invariant_gradient(demon_ctx *c, float *out, const float *in,
     if (!out || !in || !deltas || !weights || nc < 1 || h < 1 || w < 1 || ndeltas < 1 || ndeltas > 8)
         return fail(c, DEMON_ERR_INVALID, "bad argument (1..8 deltas)");
     const size_t hw = (size_t)h * w;
-    float *d_in = tmp.upload(in, nc * hw), *d_out = tmp.alloc(2 * nc * hw);
+    float *d_in = tmp.upload(in, nc * hw), *d_out = tmp.alloc(2 * ndeltas * nc * hw);
     if (!d_in || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
     launch_sig(d_out, d_in, nc, h, w, deltas, weights, ndeltas, epsilon, c->stream);
-    OP_FINISH(c, d_out, out, 2 * nc * hw);
+    OP_FINISH(c, d_out, out, 2 * ndeltas * nc * hw);
+}
+
+int demon_op_depth_to_normals(demon_ctx *c, float *out, const float *depth, const float *intrinsics, int n, int h, int w,
+                              int inverse_depth)
+{
+    OP_PROLOGUE(c);
+    if (!out || !depth || !intrinsics || n < 1 || h < 1 || w < 1) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    const size_t hw = (size_t)h * w;
+    float *d_depth = tmp.upload(depth, n * hw), *d_k = tmp.upload(intrinsics, 4 * n), *d_out = tmp.alloc(3 * n * hw);
+    if (!d_depth || !d_k || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    launch_depth_to_normals(d_out, d_depth, d_k, n, h, w, inverse_depth, c->stream);
+    OP_FINISH(c, d_out, out, 3 * n * hw);
 }
 
 int demon_op_median3x3_downsample(demon_ctx *c, float *out, const float *in, int nc, int h, int w)

@@ -176,6 +176,8 @@ void launch_replace_nonfinite(float *out, const float *in, long count, float val
 void launch_sig(float *out, const float *in, int NC, int H, int W, const int *deltas, const float *weights,
                 int ndeltas, float eps, hipStream_t s);
 void launch_median3x3_downsample(float *out, const float *in, int NC, int H, int W, hipStream_t s);
+void launch_depth_to_normals(float *out, const float *depth, const float *intrinsics, int N, int H, int W, int inverse_depth,
+                             hipStream_t s);
 void launch_pointwise_l2_partial(float *partial, const float *inp, const float *gt, int N, int C, int HW, float epsilon, hipStream_t s);
 // copies C channels of a view into another view (same H, W)
 void launch_copy_channels(float *dst, long dst_n_stride, const float *src, long src_n_stride, int N, int C,

@@ -10,7 +10,8 @@
 //   leaky_relu                       helpers.py:60-63
 //   replace_nonfinite                v2/losses.py:49
 //   scale_invariant_gradient         v2/losses.py:76-79
-//   median3x3_downsample             examples/evaluation.py:173
+//   median3x3_downsample             examples/evaluation.py:173, v2/helpers.py:102
+//   depth_to_normals                 v2/losses.py:336-337
 #include <stdlib.h>
 
 #include "internal.h"
@@ -378,26 +379,39 @@ __global__ __launch_bounds__(256) void sig_kernel(float *__restrict__ out, const
     if (x >= W || y >= H) return;
     auto at = [&](int yy, int xx) { return staged ? tile[(yy - ty0 + halo) * tw + (xx - tx0 + halo)] : p[yy * W + xx]; };
     const float u = at(y, x);
-    float gx = 0.0f, gy = 0.0f;
+    // channel = (z * ndeltas + k) * 2 + {x, y}: one gradient pair per delta (v2/losses.py:76-79 concatenates one-delta calls)
     for (int k = 0; k < sp.n; ++k) {
         const int d = sp.deltas[k];
+        float gx = 0.0f, gy = 0.0f;
         if (x + d >= 0 && x + d < W) {
             const float un = at(y, x + d);
-            gx += sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
+            gx = sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
         }
         if (y + d >= 0 && y + d < H) {
             const float un = at(y + d, x);
-            gy += sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
+            gy = sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
         }
+        out[(((long)z * sp.n + k) * 2 + 0) * H * W + y * W + x] = gx;
+        out[(((long)z * sp.n + k) * 2 + 1) * H * W + y * W + x] = gy;
     }
-    out[((long)z * 2 + 0) * H * W + y * W + x] = gx;
-    out[((long)z * 2 + 1) * H * W + y * W + x] = gy;
 }
 
-__device__ __forceinline__ void cswap(float &a, float &b)
+// Median keys: a monotone map of float bits to unsigned (negative values reversed, sign bit flipped) with every NaN mapped
+// behind +inf, so that integer min / max sort in the oracle's total order ("NaN sorts last", oracle/demon_oracle.c cmp_float).
+__device__ __forceinline__ unsigned median_key(float v)
 {
-    const float lo = fminf(a, b), hi = fmaxf(a, b);
-    // fminf/fmaxf drop NaNs; keep ordering semantics of (x>y)-(x<y) sort for finite data
+    const unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;  // NaN
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float median_unkey(unsigned k)
+{
+    if (k == 0xffffffffu) return __builtin_nanf("");
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ void cswap(unsigned &a, unsigned &b)
+{
+    const unsigned lo = min(a, b), hi = max(a, b);
     a = lo;
     b = hi;
 }
@@ -410,14 +424,14 @@ __global__ __launch_bounds__(256) void median3x3_downsample_kernel(float *__rest
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= Wo || y >= Ho) return;
     const float *p = in + (long)z * H * W;
-    float v[9];
+    unsigned v[9];
     int k = 0;
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             const int yy = min(max(2 * y + dy, 0), H - 1), xx = min(max(2 * x + dx, 0), W - 1);
-            v[k++] = p[yy * W + xx];
+            v[k++] = median_key(p[yy * W + xx]);
         }
     // median-of-9 network (Paeth)
     cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
@@ -427,7 +441,59 @@ __global__ __launch_bounds__(256) void median3x3_downsample_kernel(float *__rest
     cswap(v[3], v[6]); cswap(v[1], v[4]); cswap(v[2], v[5]);
     cswap(v[4], v[7]); cswap(v[4], v[2]); cswap(v[6], v[4]);
     cswap(v[4], v[2]);
-    out[(long)z * Ho * Wo + y * Wo + x] = v[4];
+    out[(long)z * Ho * Wo + y * Wo + x] = median_unkey(v[4]);
+}
+
+// sops.depth_to_normals (v2/losses.py:336-337): camera-frame normals from a depth map; same operation order as
+// ref_depth_to_normals in oracle/demon_oracle.c (semantics documented there; unpinned).
+// grid: (ceil(W/64), ceil(H/4), N)
+__global__ __launch_bounds__(256) void depth_to_normals_kernel(float *__restrict__ out, const float *__restrict__ depth,
+                                                               const float *__restrict__ intrinsics, int H, int W,
+                                                               int inverse_depth)
+{
+    const int n = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const int hw = H * W;
+    const float *K = intrinsics + 4 * n;
+    const float fx = K[0] * W, fy = K[1] * H, cx = K[2] * W, cy = K[3] * H;
+    const float ifx = 1.0f / fx, ify = 1.0f / fy;
+    const float *D = depth + (long)n * hw;
+    float nx = __builtin_nanf(""), ny = nx, nz = nx;
+    if (x > 0 && y > 0 && x < W - 1 && y < H - 1) {
+        const int xs[5] = {x, x - 1, x + 1, x, x}, ys[5] = {y, y, y, y - 1, y + 1};
+        float P[5][3];
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float d = D[ys[k] * W + xs[k]];
+            if (inverse_depth) d = 1.0f / d;
+            if (!(d > 0.0f) || !isfinite(d)) ok = false;
+            P[k][0] = d * ((xs[k] + 0.5f - cx) * ifx);
+            P[k][1] = d * ((ys[k] + 0.5f - cy) * ify);
+            P[k][2] = d;
+        }
+        if (ok) {
+            float dx[3], dy[3];
+            const bool bx = fabsf(P[0][2] - P[1][2]) < fabsf(P[2][2] - P[0][2]);
+            const bool by = fabsf(P[0][2] - P[3][2]) < fabsf(P[4][2] - P[0][2]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dx[c] = bx ? P[0][c] - P[1][c] : P[2][c] - P[0][c];
+                dy[c] = by ? P[0][c] - P[3][c] : P[4][c] - P[0][c];
+            }
+            const float c0 = dy[1] * dx[2] - dy[2] * dx[1];
+            const float c1 = dy[2] * dx[0] - dy[0] * dx[2];
+            const float c2 = dy[0] * dx[1] - dy[1] * dx[0];
+            const float inv = 1.0f / sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+            nx = c0 * inv; ny = c1 * inv; nz = c2 * inv;
+        }
+    }
+    float *o = out + (long)n * 3 * hw + y * W + x;
+    o[0] = nx;
+    o[hw] = ny;
+    o[2 * hw] = nz;
 }
 
 // grid: (ceil(C*HW/1024), N)
@@ -574,6 +640,13 @@ void launch_median3x3_downsample(float *out, const float *in, int NC, int H, int
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     dim3 grid((Wo + 63) / 64, (Ho + 3) / 4, NC);
     hipLaunchKernelGGL(median3x3_downsample_kernel, grid, dim3(256), 0, s, out, in, H, W, Ho, Wo);
+}
+
+void launch_depth_to_normals(float *out, const float *depth, const float *intrinsics, int N, int H, int W, int inverse_depth,
+                             hipStream_t s)
+{
+    dim3 grid((W + 63) / 64, (H + 3) / 4, N);
+    hipLaunchKernelGGL(depth_to_normals_kernel, grid, dim3(256), 0, s, out, depth, intrinsics, H, W, inverse_depth);
 }
 
 void launch_copy_channels(float *dst, long dst_n_stride, const float *src, long src_n_stride, int N, int C, long HW,

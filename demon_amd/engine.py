@@ -40,6 +40,20 @@ class DemonContext:
         self.device, self.max_batch, self.H, self.W = device, max_batch, height, width
         self.h2, self.w2, self.h5, self.w5 = height // 4, width // 4, height // 32, width // 32
 
+    @classmethod
+    def ops_only(cls, device=0):
+        """demon_create_ops: a context with a stream and the split-K workspace only, for the demon_op_* entry points"""
+        self = cls.__new__(cls)
+        self.lib = _lib.load()
+        self.h = ctypes.c_void_p()
+        self.version = 0
+        rc = self.lib.demon_create_ops(ctypes.byref(self.h), device)
+        if rc != 0:
+            raise DemonError("demon_create_ops failed (%d): %s" % (rc, self.lib.demon_last_error(None).decode()))
+        self.device, self.max_batch, self.H, self.W = device, 0, 0, 0
+        self.h2 = self.w2 = self.h5 = self.w5 = 0
+        return self
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.demon_destroy(self.h)
@@ -270,14 +284,27 @@ class DemonContext:
         return out
 
     def scale_invariant_gradient(self, x, deltas=(1,), weights=(1.0,), epsilon=0.001):
+        """[N,C,H,W] -> [N, C*2*len(deltas), H, W], channel (c*len(deltas) + k)*2 + {0: x, 1: y} (one delta and C = 1: the
+        [N,2,H,W] tensor the reference concatenates and slices in pairs, v2/losses.py:76-79, :99-102)"""
         x = _f32(x)
         n, c, h, w = x.shape
         d = np.ascontiguousarray(deltas, np.int32)
         wt = _f32(weights, (len(d),), "weights")
-        out = np.empty((n * c, 2, h, w), np.float32)
+        out = np.empty((n, c * 2 * len(d), h, w), np.float32)
         self._check(self.lib.demon_op_scale_invariant_gradient(
             self.h, _fp(out), _fp(x), n * c, h, w, d.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(wt), len(d),
             float(epsilon)))
+        return out
+
+    def depth_to_normals(self, depth, intrinsics, inverse_depth=False):
+        """v2/losses.py:336-337: [N,1,H,W] depth -> [N,3,H,W] camera-frame normals (NaN at the border / invalid depth)"""
+        depth = _f32(depth)
+        n, c, h, w = depth.shape
+        if c != 1:
+            raise DemonError("depth_to_normals: depth must have one channel")
+        intrinsics = _f32(np.broadcast_to(np.asarray(intrinsics, np.float32), (n, 4)))
+        out = np.empty((n, 3, h, w), np.float32)
+        self._check(self.lib.demon_op_depth_to_normals(self.h, _fp(out), _fp(depth), _fp(intrinsics), n, h, w, int(inverse_depth)))
         return out
 
     def median3x3_downsample(self, x):

@@ -37,10 +37,8 @@ class _Net:
         self.session = session
         self.data_format = data_format
         self.batch_size = batch_size
-        self._ctx = runtime.get_context(batch_size, _H, _W, version=self._version)
-        w = getattr(session, "demon_weights", None)
-        if w is not None:
-            self._ctx.set_weights(w)
+        # a session that carries its own variables (python/tf_stub) owns its context; Saver.restore fills it later
+        self._ctx = runtime.get_context(batch_size, _H, _W, version=self._version, session=session)
 
     def _shape(self, c, h, w):
         n = self.batch_size

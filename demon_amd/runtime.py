@@ -18,7 +18,7 @@ def set_default_weights(weights):
     version = weights_version(weights)
     _default_weights[version] = weights
     for ctx in _contexts.values():
-        if ctx.version == version:
+        if ctx.version == version and getattr(ctx, "_owner", None) is None:   # session-owned contexts keep their own set
             ctx.set_weights(weights)
 
 
@@ -26,23 +26,64 @@ def default_weights(version=1):
     return _default_weights[version]
 
 
-def get_context(batch_size=1, height=192, width=256, device=None, version=1):
+def _owner(session):
+    """sessions that carry their own variables (python/tf_stub: an object with a `demon_weights` attribute) own their contexts,
+    like a tf.Session owns its variables; anything else (None, a real tf.Session) shares the process default"""
+    return session if session is not None and hasattr(session, "demon_weights") else None
+
+
+def get_context(batch_size=1, height=192, width=256, device=None, version=1, session=None):
+    """One context per (device, batch, size, model version, owning session).  Nets built on different weight-carrying
+    sessions get different contexts, so restoring a checkpoint into one session does not replace the weights of nets built
+    on another (the reference's variables live in the tf.Session, examples/example.py:70-83)."""
     if device is None:
         device = int(os.environ.get("DEMON_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    key = (device, batch_size, height, width, version)
+    owner = _owner(session)
+    key = (device, batch_size, height, width, version, id(owner) if owner is not None else 0)
     ctx = _contexts.get(key)
     if ctx is None:
         ctx = DemonContext(device, batch_size, height, width, version)
         if os.environ.get("DEMON_HIPGRAPH", "1") == "0":
             ctx.set_option("hipgraph", 0)
         ctx.load_tuned_plan(batch_size)   # measured launch plan for this shape, when one is shipped (demon_amd/tuned)
-        if _default_weights[version] is not None:
-            ctx.set_weights(_default_weights[version])
+        w = owner.demon_weights if owner is not None and owner.demon_weights is not None else _default_weights[version]
+        if w is not None:
+            ctx.set_weights(w)
+        ctx._owner = owner   # keeps the session alive, so its id stays unique while the context exists
         _contexts[key] = ctx
     return ctx
 
 
-def release_all():
+def set_session_weights(session, weights):
+    """Saver.restore(session, ...) of python/tf_stub: the weights become the session's variables and go to every context the
+    session owns (nets are constructed before restore(), examples/example.py:75-83).  They also become the process default
+    when there is none yet, for nets built without a session."""
+    from .weights import weights_version
+    version = weights_version(weights)
+    session.demon_weights = weights
     for ctx in _contexts.values():
+        if ctx.version == version and getattr(ctx, "_owner", None) is session:
+            ctx.set_weights(weights)
+    if _default_weights[version] is None:
+        set_default_weights(weights)
+
+
+_ops_contexts = {}
+
+
+def get_ops_context(device=None):
+    """Stream + workspace only (demon_create_ops): what the lmbspecialops-level entry points need.  No network, no
+    activation arena, no packed weights."""
+    if device is None:
+        device = int(os.environ.get("DEMON_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    ctx = _ops_contexts.get(device)
+    if ctx is None:
+        ctx = _ops_contexts[device] = DemonContext.ops_only(device)
+    return ctx
+
+
+def release_all():
+    for ctx in list(_contexts.values()) + list(_ops_contexts.values()):
         ctx.close()
     _contexts.clear()
+    _ops_contexts.clear()

@@ -1,7 +1,7 @@
 """Mirror of the `lmbspecialops` Python API (the op set the reference calls) on
 numpy arrays, executed by the HIP kernels of libdemon_hip.so.  Argument names / order follow the
 reference's call sites (python/depthmotionnet/blocks_original.py:155-176, :336-360; v2/blocks.py:362;
-v2/losses.py:49, :78; examples/evaluation.py:173).  All image tensors are NCHW float32.
+v2/losses.py:49, :78, :336; examples/evaluation.py:173).  All image tensors are NCHW float32.
 """
 import numpy as np
 
@@ -9,11 +9,13 @@ from . import runtime
 
 
 def _ctx():
-    return runtime.get_context(1)
+    return runtime.get_ops_context()
 
 
-def depth_to_flow(intrinsics, depth, rotation, translation, rotation_format="angleaxis3", inverse_depth=False,
-                  normalize_flow=False):
+def depth_to_flow(depth, intrinsics, rotation, translation, rotation_format="angleaxis3", inverse_depth=False,
+                  normalize_flow=False, name=None):
+    """positional order of the reference's positional call sites (examples/evaluation.py:81, v2/losses.py:332-334); the network
+    code passes keywords (blocks_original.py:155-162)"""
     if rotation_format != "angleaxis3":
         raise ValueError("only rotation_format='angleaxis3' is supported")
     return _ctx().depth_to_flow(depth, intrinsics, rotation, translation, inverse_depth, normalize_flow)
@@ -53,3 +55,7 @@ def scale_invariant_gradient(input, deltas=(1,), weights=(1.0,), epsilon=0.001):
 
 def median3x3_downsample(input):
     return _ctx().median3x3_downsample(input)
+
+
+def depth_to_normals(depth, intrinsics, inverse_depth=False):
+    return _ctx().depth_to_normals(depth, intrinsics, inverse_depth)

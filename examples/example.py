@@ -22,23 +22,7 @@ from depthmotionnet.networks_original import BootstrapNet, IterativeNet, Refinem
 from depthmotionnet.helpers import angleaxis_to_rotation_matrix  # noqa: E402
 
 
-def prepare_input_data(img1, img2, data_format):
-    """PIL images -> network inputs in [-0.5, 0.5] (reference examples/example.py:15-42).  The reference relies on
-    PIL's default resize filter, which changed between Pillow versions (SURVEY hazard H3): NEAREST is used here, the
-    default of the Pillow 2.0.0 the reference pins (Dockerfile:15)."""
-    from PIL import Image
-    if img1.size != (256, 192):
-        img1 = img1.resize((256, 192), Image.NEAREST)
-    if img2.size != (256, 192):
-        img2 = img2.resize((256, 192), Image.NEAREST)
-    img2_2 = img2.resize((64, 48), Image.NEAREST)
-    arrs = [np.asarray(im.convert("RGB"), dtype=np.float32) / 255 - 0.5 for im in (img1, img2, img2_2)]
-    if data_format == "channels_first":
-        arrs = [a.transpose(2, 0, 1) for a in arrs]
-        pair = np.concatenate(arrs[:2], axis=0)
-    else:
-        pair = np.concatenate(arrs[:2], axis=-1)
-    return {"image_pair": pair[np.newaxis], "image1": arrs[0][np.newaxis], "image2_2": arrs[2][np.newaxis]}
+from demon_amd.preprocess import prepare_input_data  # noqa: E402  (reference examples/example.py:15-42)
 
 
 def main():
@@ -61,7 +45,7 @@ def main():
         w = load_tf_checkpoint(args.weights, list(W.variable_shapes()))
     demon_amd.set_default_weights(w)
 
-    data = prepare_input_data(Image.open(args.img1), Image.open(args.img2), args.data_format)
+    data = prepare_input_data(Image.open(args.img1).convert("RGB"), Image.open(args.img2).convert("RGB"), args.data_format)
     bootstrap_net = BootstrapNet(None, args.data_format)
     iterative_net = IterativeNet(None, args.data_format)
     refine_net = RefinementNet(None, args.data_format)

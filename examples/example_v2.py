@@ -44,7 +44,7 @@ def main():
         ap.error("--checkpoint or --synthetic is required (the reference ships no v2 weights)")
     demon_amd.set_default_weights(w)
 
-    data = prepare_input_data(Image.open(args.img1), Image.open(args.img2), "channels_first")
+    data = prepare_input_data(Image.open(args.img1).convert("RGB"), Image.open(args.img2).convert("RGB"), "channels_first")
     bootstrap_net, iterative_net, refine_net = BootstrapNet(None), IterativeNet(None), RefinementNet(None)
     result = bootstrap_net.eval(data["image_pair"], data["image2_2"])
     for _ in range(3):

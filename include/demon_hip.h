@@ -59,6 +59,10 @@ int demon_create(demon_ctx **ctx, int device, int max_batch, int height, int wid
  * flow_to_depth2 + clip [0,50], predict_normal0).  Every other entry point works on such a context unchanged; the variable table
  * (demon_variable_info) is the v2 one.  demon_variant returns 1 or 2.                                                        */
 int demon_create_v2(demon_ctx **ctx, int device, int max_batch, int height, int width);
+/* A context without networks: one HIP stream and the split-K workspace, all the demon_op_* entry points below need
+ * (replaces `import lmbspecialops` = tf.load_op_library($LMBSPECIALOPS_LIB), Dockerfile:26-27, for op-only callers).
+ * Network entry points return DEMON_ERR_INVALID on it. */
+int demon_create_ops(demon_ctx **ctx, int device);
 int demon_variant(const demon_ctx *ctx);
 int demon_destroy(demon_ctx *ctx);
 const char *demon_last_error(const demon_ctx *ctx); /* ctx may be NULL: error of a failed create */
@@ -148,8 +152,9 @@ int demon_profile_full(demon_ctx *ctx, int n, int iterations, int repeats, demon
  *   warp2d                   blocks_original.py:171-176, :336   (border_mode 0 clamp, 1 value)
  *   leaky_relu               helpers.py:60-63
  *   replace_nonfinite        v2/losses.py:49
- *   scale_invariant_gradient v2/losses.py:76-79
- *   median3x3_downsample     examples/evaluation.py:173                                              */
+ *   scale_invariant_gradient v2/losses.py:76-79   out [nc * ndeltas * 2, h, w]: channel (z*ndeltas + k)*2 + {x, y}
+ *   median3x3_downsample     examples/evaluation.py:173, v2/helpers.py:102   (NaN sorts last)
+ *   depth_to_normals         v2/losses.py:336-337   out [n, 3, h, w], NaN at the border / invalid depth   */
 int demon_op_depth_to_flow(demon_ctx *ctx, float *out, const float *depth, const float *intrinsics,
                            const float *rotation, const float *translation, int n, int h, int w,
                            int inverse_depth, int normalize_flow, int gate);
@@ -163,6 +168,8 @@ int demon_op_replace_nonfinite(demon_ctx *ctx, float *out, const float *in, int6
 int demon_op_scale_invariant_gradient(demon_ctx *ctx, float *out, const float *in, int nc, int h, int w,
                                       const int *deltas, const float *weights, int ndeltas, float epsilon);
 int demon_op_median3x3_downsample(demon_ctx *ctx, float *out, const float *in, int nc, int h, int w);
+int demon_op_depth_to_normals(demon_ctx *ctx, float *out, const float *depth, const float *intrinsics, int n, int h, int w,
+                              int inverse_depth);
 /* pointwise_l2_loss of v2/losses.py:33-54 (NCHW): mean over pixels of sqrt(sum_c replace_nonfinite(inp - gt)^2 + epsilon) */
 int demon_op_pointwise_l2_loss(demon_ctx *ctx, float *loss, const float *inp, const float *gt, int n, int c, int h, int w,
                                float epsilon);

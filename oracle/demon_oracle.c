@@ -17,10 +17,21 @@
  *     routines :9-59, :108-161;
  *   - flow_to_depth (both methods): applied to that reference flow they return the reference's depth;
  *   - the angle-axis convention of python/depthmotionnet/helpers.py:37-57.
- * Still unpinned: warp2d's border / rounding rules, scale_invariant_gradient, median3x3_downsample,
- * and every TensorFlow layer (conv2d 'valid' on a padded input, conv2d_transpose, dense, 'same'
- * padding of the v2 model): they restate published semantics at the reference's call sites, which each
- * function cites.
+ *   - a SECOND restatement of the depth -> flow geometry, from a different reference file written in the world frame
+ *     (multivih5datareaderop/multivih5datareader.cpp:369-424 / :431-501 -> oracle/reader_ref.py), agrees with that golden flow,
+ *     with the reference's visibility mask and with ref_depth_to_flow fed the relative motion (tests/test_pins.py);
+ *   - warp2d's displacement SIGN, CHANNEL ORDER (0 = x) and NORMALISATION (normalized: flow / (W, H)): pulling sculpture image 2
+ *     back by the reference flow reproduces image 1 on the reference's visible mask (NCC 0.64 vs 0.25 unwarped, 0.06 negated);
+ *     the sub-pixel convention (sample at index x + dx) is pinned only by the zero-displacement identity -- the photo pair is
+ *     too noisy to separate half-pixel shifts (tests/test_pins.py, tests/test_ops_gpu.py::test_photometric_warp_kat_hip);
+ *   - prepare_input_data (examples/example.py:15-42) is pinned bit for bit to the reference function run here
+ *     (tests/golden/make_golden_inputs.py, tests/test_preprocess.py) -- host code, listed for completeness.
+ * Still unpinned (no in-tree material constrains them; each function states the rule it implements):
+ *   warp2d's treatment of taps outside the image and of non-finite displacements, flow_to_depth on geometrically
+ *   inconsistent flow (DLT vs closed form), scale_invariant_gradient (border rule, layout for C > 1), median3x3_downsample
+ *   (NaN ordering: "NaN sorts last" here), depth_to_normals (difference scheme, orientation), and every TensorFlow layer
+ *   (conv2d 'valid' on a padded input, conv2d_transpose, dense, 'same' padding of the v2 model; checked against PyTorch and
+ *   naive loops only): they restate published semantics at the reference's call sites, which each function cites.
  *
  * All tensors are NCHW float32, contiguous.
  */
@@ -264,9 +275,12 @@ void ref_replace_nonfinite(float *out, const float *in, size_t count, float valu
 }
 
 /* ---------------------------------------------------------------------------------------------
- * sops.scale_invariant_gradient -- v2/losses.py:76-79 (one delta per call there).
- * in [N,C,H,W] -> out [N*C, 2, H, W];  gx = sum_d w_d*(u(x+d,y)-u(x,y))/(|u(x+d,y)|+|u(x,y)|+eps),
- * zero where the neighbour is outside the image; gy alike.
+ * sops.scale_invariant_gradient -- v2/losses.py:76-79 (one delta per call there, results concatenated
+ * on axis 1; slices of two channels are compared by scale_invariant_gradient_loss :82-104).
+ * in [N,C,H,W] -> out [N, C*2*ndeltas, H, W], channel = (c*ndeltas + k)*2 + {0: x, 1: y}:
+ *   gx_k = w_k*(u(x+d_k,y)-u(x,y))/(|u(x+d_k,y)|+|u(x,y)|+eps), zero where the neighbour is outside
+ *   the image; gy_k alike.  For one delta and C = 1 this is the [N,2,H,W] tensor of the call site.
+ * Unpinned (lmbspecialops absent): the layout for C > 1 / several deltas, the border rule.
  * ------------------------------------------------------------------------------------------- */
 void ref_scale_invariant_gradient(float *out, const float *in, int NC, int H, int W, const int *deltas,
                                   const float *weights, int ndeltas, float epsilon)
@@ -276,28 +290,32 @@ void ref_scale_invariant_gradient(float *out, const float *in, int NC, int H, in
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
                 const float u = in[(size_t)z * hw + y * W + x];
-                float gx = 0, gy = 0;
                 for (int k = 0; k < ndeltas; ++k) {
                     const int d = deltas[k];
+                    float gx = 0, gy = 0;
                     if (x + d >= 0 && x + d < W) {
                         const float un = in[(size_t)z * hw + y * W + x + d];
-                        gx += weights[k] * (un - u) / (fabsf(un) + fabsf(u) + epsilon);
+                        gx = weights[k] * (un - u) / (fabsf(un) + fabsf(u) + epsilon);
                     }
                     if (y + d >= 0 && y + d < H) {
                         const float un = in[(size_t)z * hw + (y + d) * W + x];
-                        gy += weights[k] * (un - u) / (fabsf(un) + fabsf(u) + epsilon);
+                        gy = weights[k] * (un - u) / (fabsf(un) + fabsf(u) + epsilon);
                     }
+                    out[(((size_t)z * ndeltas + k) * 2 + 0) * hw + y * W + x] = gx;
+                    out[(((size_t)z * ndeltas + k) * 2 + 1) * hw + y * W + x] = gy;
                 }
-                out[((size_t)z * 2 + 0) * hw + y * W + x] = gx;
-                out[((size_t)z * 2 + 1) * hw + y * W + x] = gy;
             }
 }
 
 /* sops.median3x3_downsample -- examples/evaluation.py:173, v2/helpers.py:102:
  * [NC,H,W] -> [NC,ceil(H/2),ceil(W/2)], median of the 3x3 window centred at (2y,2x), clamped. */
+/* total order: finite and infinite values by value, every NaN behind +inf ("NaN sorts last"), so the median of a
+ * window with up to four NaNs is a number and with five or more it is NaN.  Unpinned (lmbspecialops absent). */
 static int cmp_float(const void *a, const void *b)
 {
     const float x = *(const float *)a, y = *(const float *)b;
+    const int nx = isnan(x), ny = isnan(y);
+    if (nx || ny) return nx - ny;
     return (x > y) - (x < y);
 }
 void ref_median3x3_downsample(float *out, const float *in, int NC, int H, int W)
@@ -318,6 +336,62 @@ void ref_median3x3_downsample(float *out, const float *in, int NC, int H, int W)
                 qsort(v, 9, sizeof(float), cmp_float);
                 out[(size_t)z * Ho * Wo + y * Wo + x] = v[4];
             }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * sops.depth_to_normals -- call site v2/losses.py:336-337 (inverse_depth=True), ground-truth normals
+ * for the training loss.  depth [N,1,H,W], intrinsics (fx,fy,cx,cy) normalised -> normals [N,3,H,W] in
+ * the camera frame.  UNPINNED / [RECALL] (lmbspecialops absent, no in-tree restatement):
+ *   P(x,y) = z*((x+0.5-cx)/fx, (y+0.5-cy)/fy, 1), z = inverse_depth ? 1/d : d (pixel centre as in depth_to_flow);
+ *   border pixels and pixels whose own or 4-neighbour depths are not finite and positive give NaN;
+ *   per axis the one-sided difference (P - P(x-1), P(x+1) - P) with the smaller |dz| is used (keeps depth edges
+ *   sharp); n = normalize(diff_y x diff_x), which points towards the camera (n = (0,0,-1) for a fronto-parallel
+ *   plane).
+ * ------------------------------------------------------------------------------------------- */
+void ref_depth_to_normals(float *out, const float *depth, const float *intrinsics, int N, int H, int W, int inverse_depth)
+{
+    const int hw = H * W;
+    for (int n = 0; n < N; ++n) {
+        const float *K = intrinsics + 4 * n;
+        const float fx = K[0] * W, fy = K[1] * H, cx = K[2] * W, cy = K[3] * H;
+        const float ifx = 1.0f / fx, ify = 1.0f / fy;
+        const float *D = depth + (size_t)n * hw;
+        float *o = out + (size_t)n * 3 * hw;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float nx = NAN, ny = NAN, nz = NAN;
+                if (x > 0 && y > 0 && x < W - 1 && y < H - 1) {
+                    const int xs[5] = {x, x - 1, x + 1, x, x}, ys[5] = {y, y, y, y - 1, y + 1};
+                    float P[5][3];
+                    int ok = 1;
+                    for (int k = 0; k < 5; ++k) {
+                        float d = D[ys[k] * W + xs[k]];
+                        if (inverse_depth) d = 1.0f / d;
+                        if (!(d > 0.0f) || !isfinite(d)) ok = 0;
+                        P[k][0] = d * ((xs[k] + 0.5f - cx) * ifx);
+                        P[k][1] = d * ((ys[k] + 0.5f - cy) * ify);
+                        P[k][2] = d;
+                    }
+                    if (ok) {
+                        float dx[3], dy[3];
+                        const int bx = fabsf(P[0][2] - P[1][2]) < fabsf(P[2][2] - P[0][2]);  /* 1: backward difference */
+                        const int by = fabsf(P[0][2] - P[3][2]) < fabsf(P[4][2] - P[0][2]);
+                        for (int c = 0; c < 3; ++c) {
+                            dx[c] = bx ? P[0][c] - P[1][c] : P[2][c] - P[0][c];
+                            dy[c] = by ? P[0][c] - P[3][c] : P[4][c] - P[0][c];
+                        }
+                        const float c0 = dy[1] * dx[2] - dy[2] * dx[1];
+                        const float c1 = dy[2] * dx[0] - dy[0] * dx[2];
+                        const float c2 = dy[0] * dx[1] - dy[1] * dx[0];
+                        const float inv = 1.0f / sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+                        nx = c0 * inv; ny = c1 * inv; nz = c2 * inv;
+                    }
+                }
+                o[0 * hw + y * W + x] = nx;
+                o[1 * hw + y * W + x] = ny;
+                o[2 * hw + y * W + x] = nz;
+            }
+    }
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -97,9 +97,19 @@ def scale_invariant_gradient(x, deltas=(1,), weights=(1.0,), epsilon=0.001):
     N, C, H, W = x.shape
     d = np.ascontiguousarray(deltas, np.int32)
     w, pw = _f(weights)
-    out = np.empty((N * C, 2, H, W), np.float32)
+    out = np.empty((N, C * 2 * len(d), H, W), np.float32)
     lib().ref_scale_invariant_gradient(out.ctypes.data_as(_f32p), px, N * C, H, W, d.ctypes.data_as(_i32p), pw,
                                        len(d), ctypes.c_float(epsilon))
+    return out
+
+
+def depth_to_normals(depth, intrinsics, inverse_depth=False):
+    depth, pd = _f(depth)
+    N, C, H, W = depth.shape
+    assert C == 1
+    intrinsics, pi = _f(np.broadcast_to(intrinsics, (N, 4)))
+    out = np.empty((N, 3, H, W), np.float32)
+    lib().ref_depth_to_normals(out.ctypes.data_as(_f32p), pd, pi, N, H, W, int(inverse_depth))
     return out
 
 

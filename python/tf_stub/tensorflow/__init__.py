@@ -62,7 +62,6 @@ def global_variables_initializer():
 
 class _Saver:
     def restore(self, session, save_path):
-        import demon_amd
         from demon_amd import weights as W
         if os.path.exists(save_path + ".index"):
             from demon_amd.tf_checkpoint import load_tf_checkpoint, read_index
@@ -75,8 +74,10 @@ class _Saver:
             w = W.synthetic_weights(seed=1, version=int(os.environ["DEMON_SYNTHETIC_WEIGHTS"]))
         else:
             raise IOError("checkpoint %s(.index|.npz) not found (set DEMON_SYNTHETIC_WEIGHTS=1 / =2 for random weights of the original / v2 model)" % save_path)
-        session.demon_weights = w
-        demon_amd.set_default_weights(w)  # networks constructed before restore() pick the weights up here
+        # the weights become this session's variables: networks constructed on it before restore() pick them up here, nets of
+        # other sessions keep theirs; the first restored set also becomes the process default
+        from demon_amd import runtime
+        runtime.set_session_weights(session, w)
 
 
 class _Train:

@@ -71,6 +71,8 @@ def test_tensorflow_stub_restores_weights(tmp_path):
         assert "stub" in tf.__version__
         from demon_amd import weights as W, tf_checkpoint as ck
         import demon_amd
+        from demon_amd import runtime
+        runtime._default_weights[1] = runtime._default_weights[2] = None   # the first restored set becomes the default
         w = {k: np.full(s, 0.25, np.float32) for k, s in W.variable_shapes().items()}
         prefix = str(tmp_path / "demon_original")
         ck.save_tf_checkpoint(prefix, w)
@@ -96,5 +98,5 @@ def test_tensorflow_stub_restores_weights(tmp_path):
     finally:
         sys.path.remove(os.path.join(ROOT, "python", "tf_stub"))
         sys.modules.pop("tensorflow", None)
-        import demon_amd
-        demon_amd.set_default_weights(None) if False else None
+        from demon_amd import runtime
+        runtime._default_weights[1] = runtime._default_weights[2] = None

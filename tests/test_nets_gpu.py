@@ -58,13 +58,38 @@ def test_iterative_gate_and_nan_inputs(gpu_ctx, ref):
     pair, img2_2 = make_inputs(2, seed=6)
     depth2 = np.full((2, 1, 48, 64), 0.5, np.float32)
     depth2[0, 0, :10] = -1.0        # invalid inverse depth -> NaN flow -> gated to 0
-    depth2[1, 0, 5, 5] = np.nan
+    depth2[1, 0, 5, 5] = 0.0        # 1 / 0 = inf depth -> NaN flow -> gated to 0
     normal2 = np.zeros((2, 3, 48, 64), np.float32)
-    depth2[1, 0, 5, 5] = 0.0
     rot = np.array([[0.0, 0.0, 0.0], [0.3, -0.2, 0.1]], np.float32)
     tr = np.array([[5.0, 0.0, 0.0], [0.1, 0.9, -0.2]], np.float32)  # huge translation -> |flow| >= 1 -> 0
     args = (pair, img2_2, depth2, normal2, rot, tr)
-    _cmp(gpu_ctx.iterative(*args), ref.iterative(*args), KEYS)
+    got = gpu_ctx.iterative(*args)
+    assert all(np.isfinite(got[k]).all() for k in KEYS)
+    _cmp(got, ref.iterative(*args), KEYS)
+
+
+def test_iterative_nan_input_propagates_like_the_oracle(gpu_ctx, ref):
+    """A NaN in the fed depth2 is NOT absorbed by the gate: the gate only zeroes the flow computed from it
+    (blocks_original.py:163-168) while depth2 itself is a conv input (:180), so NaN spreads through the net -- on both sides
+    alike.  Sample 0 carries the NaN, sample 1 is clean and must be unaffected (pairs are independent)."""
+    pair, img2_2 = make_inputs(2, seed=16)
+    depth2 = np.full((2, 1, 48, 64), 0.5, np.float32)
+    depth2[0, 0, 5, 5] = np.nan
+    normal2 = np.zeros((2, 3, 48, 64), np.float32)
+    rot = np.array([[0.02, -0.01, 0.03], [0.3, -0.2, 0.1]], np.float32)
+    tr = np.array([[0.5, 0.1, 0.0], [0.1, 0.9, -0.2]], np.float32)
+    args = (pair, img2_2, depth2, normal2, rot, tr)
+    got, want = gpu_ctx.iterative(*args), ref.iterative(*args)
+    for k in KEYS:
+        assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), k
+        assert np.isnan(want[k][0]).any(), k                         # the NaN reaches every output of its own sample
+        assert np.isfinite(got[k][1]).all(), k                       # ... and none of the other sample
+        assert rel_l1(got[k][1], want[k][1]) < 1e-3, k
+    clean = depth2.copy()
+    clean[0, 0, 5, 5] = 0.5
+    alone = gpu_ctx.iterative(pair, img2_2, clean, normal2, rot, tr)
+    for k in KEYS:
+        np.testing.assert_array_equal(alone[k][1], got[k][1])        # bit-identical: no cross-sample leakage
 
 
 def test_refine(gpu_ctx, ref):
