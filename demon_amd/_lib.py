@@ -33,6 +33,11 @@ SIGNATURES = {
     "demon_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "demon_create_v2": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "demon_create_ops": (_I, [ctypes.POINTER(_P), _I]),
+    "demon_comm_get_unique_id": (_I, [ctypes.c_char_p]),
+    "demon_comm_init_rank": (_I, [ctypes.POINTER(_P), _I, ctypes.c_char_p, _I, _I]),
+    "demon_comm_destroy": (_I, [_P]),
+    "demon_broadcast_weights": (_I, [_P, _P, _I, _I]),
+    "demon_weights_slab_bytes": (ctypes.c_int64, [_P]),
     "demon_variant": (_I, [_P]),
     "demon_destroy": (_I, [_P]),
     "demon_last_error": (ctypes.c_char_p, [_P]),

@@ -11,6 +11,17 @@ SOURCES = ["demon_api.hip", "conv_mfma.hip", "conv_patch.hip", "conv_small.hip",
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
+def csrc_sha():
+    """sha1 over the kernel sources: stamps profiles (tools/pmc_summary.py) so that bench.py can tell a counter summary
+    measured on these kernels from a stale one"""
+    import hashlib
+    h = hashlib.sha1()
+    for name in sorted(SOURCES) + ["internal.h"]:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):

@@ -6,6 +6,8 @@
 // their concat buffers, and each sequence is captured into a hipGraph.  Nothing is allocated and no
 // host round trip happens between the stages of examples/example.py:87-99.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library itself is dlopen'ed on first use (see rccl() below)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -26,6 +28,17 @@ using namespace demon;
 namespace {
 
 thread_local std::string g_create_error;
+// kernel family the last run_layer / run_pair call launched ("conv_mfma", "conv_patch", "deconv4", "conv_small", "conv_pair",
+// with "+splitk" when a split-K reduce launch follows); demon_profile_full reads it to attribute time per kernel
+thread_local const char *g_last_kernel = nullptr;
+thread_local char g_kernel_tag[32];
+void set_kernel_tag(const char *family, int bm, int bn, int taps, bool splitk)
+{
+    // e.g. "conv_mfma<128x32>+splitk" (rocprofv3: conv_mfma_kernel<128, 32, ...>), "conv_patch<64x128,t5>", "deconv4<32x128>"
+    if (taps > 0) snprintf(g_kernel_tag, sizeof g_kernel_tag, "%s<%dx%d,t%d>%s", family, bm, bn, taps, splitk ? "+splitk" : "");
+    else snprintf(g_kernel_tag, sizeof g_kernel_tag, "%s<%dx%d>%s", family, bm, bn, splitk ? "+splitk" : "");
+    g_last_kernel = g_kernel_tag;
+}
 
 struct Layer {
     std::string name;  // "<scope>/<layer>"
@@ -95,6 +108,10 @@ struct demon_ctx {
     std::vector<hipEvent_t> events;  // fork / join events, one per use inside a sequence
     int opt_side_branches = 1;
     int opt_fused_pairs = 1;  // conv_pair.hip for the pairs conv_pair_applies() selects
+    // all packed kernels and biases of the networks live in ONE device slab (alloc_weight_slab), so that
+    // demon_broadcast_weights is a single RCCL broadcast of device-resident, already packed data
+    float *w_slab = nullptr;
+    size_t w_slab_floats = 0;
 };
 
 namespace {
@@ -159,7 +176,7 @@ void add_variable(demon_ctx *c, Layer *L, bool is_bias)
 }
 
 // ---- layer planning (geometry, K table) ------------------------------------------------------------
-bool plan_layer(demon_ctx *c, Layer *L)
+bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
 {
     const int H = L->in.H, W = L->in.W;
     std::vector<KEntry> tab;
@@ -204,12 +221,33 @@ bool plan_layer(demon_ctx *c, Layer *L)
     }
     L->d_ktab = (KEntry *)dev_alloc(c, tab.size() * sizeof(KEntry));
     L->Krows = L->Kpad + 16;  // 16 zero rows of slack: the patch kernel's last channel chunk may read past K
+    if (!L->d_ktab) return false;
+    if (hipMemcpy(L->d_ktab, tab.data(), tab.size() * sizeof(KEntry), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (!alloc_weights) return true;  // network layers: alloc_weight_slab() places d_wp / d_bias once all layers exist
     L->d_wp = dev_alloc(c, sizeof(float) * (size_t)L->ncls * L->Krows * L->Mpad);
     L->d_bias = dev_alloc(c, sizeof(float) * L->Mpad);
-    if (!L->d_ktab || !L->d_wp || !L->d_bias) return false;
-    if (hipMemcpy(L->d_ktab, tab.data(), tab.size() * sizeof(KEntry), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (!L->d_wp || !L->d_bias) return false;
     if (hipMemset(L->d_wp, 0, sizeof(float) * (size_t)L->ncls * L->Krows * L->Mpad) != hipSuccess) return false;
     if (hipMemset(L->d_bias, 0, sizeof(float) * L->Mpad) != hipSuccess) return false;
+    return true;
+}
+
+// One slab for the packed kernels and biases of every network layer (zero-filled: padded rows / columns stay zero).
+bool alloc_weight_slab(demon_ctx *c)
+{
+    auto a64 = [](size_t n) { return (n + 63) / 64 * 64; };  // 256-byte aligned pieces
+    size_t total = 0;
+    for (auto &L : c->layers) total += a64((size_t)L->ncls * L->Krows * L->Mpad) + a64(L->Mpad);
+    c->w_slab = dev_alloc(c, sizeof(float) * total);
+    if (!c->w_slab || hipMemset(c->w_slab, 0, sizeof(float) * total) != hipSuccess) return false;
+    c->w_slab_floats = total;
+    size_t off = 0;
+    for (auto &L : c->layers) {
+        L->d_wp = c->w_slab + off;
+        off += a64((size_t)L->ncls * L->Krows * L->Mpad);
+        L->d_bias = c->w_slab + off;
+        off += a64(L->Mpad);
+    }
     return true;
 }
 
@@ -436,6 +474,8 @@ void launch_patch_plan(const Layer *L, PatchPlan &pp, ConvArgs &a, long P, float
 {
     while (pp.a.ksplit > 1 && (!ws || (long)L->ncls * pp.a.ksplit * L->Mpad * P > kSplitKWorkspaceFloats)) --pp.a.ksplit;
     launch_conv_patch(pp.a, pp.tile, pp.ntaps, L->ncls, s);
+    set_kernel_tag(patch_tile_is_dc4(pp.tile) ? "deconv4" : "conv_patch", patch_tile_bm(pp.tile), patch_tile_bn(pp.tile),
+                   patch_tile_is_dc4(pp.tile) ? 0 : pp.ntaps, pp.a.ksplit > 1);
     if (pp.a.ksplit > 1) {
         a.ksplit = pp.a.ksplit;
         launch_splitk_reduce(a, L->ncls, s);
@@ -454,6 +494,13 @@ void run_small(const Layer *L, const ConvArgs &a, hipStream_t s)
     sa.Cin = L->Cin; sa.Cout = L->Cout; sa.Mpad = L->Mpad; sa.H = a.H; sa.W = a.W; sa.act = a.act;
     sa.in_n_stride = a.in_n_stride; sa.out_n_stride = a.out_n_stride;
     launch_conv_small(sa, a.N, s);
+    g_last_kernel = "conv_small";
+}
+
+void run_mfma(const ConvArgs &a, ConvPlan plan, int ncls, hipStream_t s)
+{
+    launch_conv_mfma(a, plan, ncls, s);
+    set_kernel_tag("conv_mfma", conv_tile_bm(plan.tile), conv_tile_bn(plan.tile), 0, plan.ksplit > 1);
 }
 
 void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
@@ -479,7 +526,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                     return;
                 }
             } else if (tile >= 0 && tile < TILE_COUNT && L->Mpad % conv_tile_bm(tile) == 0) {
-                launch_conv_mfma(a, ConvPlan{tile, clamp_split(ks < 1 ? 1 : (ks > L->Kpad / 16 ? L->Kpad / 16 : ks))}, L->ncls, s);
+                run_mfma(a, ConvPlan{tile, clamp_split(ks < 1 ? 1 : (ks > L->Kpad / 16 ? L->Kpad / 16 : ks))}, L->ncls, s);
                 return;
             }
         }
@@ -500,7 +547,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                     return;
                 }
             } else {
-                launch_conv_mfma(a, ConvPlan{t.tile, clamp_split(t.ksplit)}, L->ncls, s);
+                run_mfma(a, ConvPlan{t.tile, clamp_split(t.ksplit)}, L->ncls, s);
                 return;
             }
         }
@@ -518,7 +565,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
     if (L->force_tile >= 0 && L->force_tile < TILE_COUNT) plan.tile = L->force_tile;
     if (L->force_split > 0) plan.ksplit = L->force_split;
     plan.ksplit = clamp_split(plan.ksplit);
-    launch_conv_mfma(a, plan, L->ncls, s);
+    run_mfma(a, plan, L->ncls, s);
 }
 
 // Measures every applicable (kernel, tile, split-K) variant of one layer at batch n and remembers the fastest.
@@ -610,7 +657,9 @@ bool run_pair(const Layer *Ly, const Layer *Lx, int n, hipStream_t s)
     a.steps2 = (a.CM + cks - 1) / cks;
     static const int xcd_order = getenv("DEMON_XCD_ORDER") ? atoi(getenv("DEMON_XCD_ORDER")) : 1;
     a.xcd = xcd_order;
-    return launch_conv_pair(a, Ly->kh, Ly->sh, s);
+    if (!launch_conv_pair(a, Ly->kh, Ly->sh, s)) return false;
+    g_last_kernel = "conv_pair";
+    return true;
 }
 
 // ---- topology builder ---------------------------------------------------------------------------------
@@ -643,7 +692,7 @@ struct Builder {
         if (kind == Layer::CONV) L->kernel_dims = {kh, kw, in.C, out.C};
         else if (kind == Layer::DECONV) L->kernel_dims = {4, 4, out.C, in.C};
         else L->kernel_dims = {in.C, out.C};
-        if (!plan_layer(c, L.get())) ok = false;
+        if (!plan_layer(c, L.get(), false)) ok = false;
         Layer *p = L.get();
         c->layers.push_back(std::move(L));
         add_variable(c, p, false);
@@ -1198,6 +1247,7 @@ static int create_impl(demon_ctx **out, int device, int max_batch, int height, i
     build_flow(p, &p->net_iter, "netFlow2", true);
     build_dm(p, &p->net_iter, "netDM2", true);
     build_refine(p, &p->net_refine);
+    if (p->err.empty() && !alloc_weight_slab(p)) p->err = "device allocation failed (weight slab)";
     if (!p->err.empty() || hipDeviceSynchronize() != hipSuccess) {
         std::string e = p->err.empty() ? "device error while building the networks" : p->err;
         demon_destroy(c.release());
@@ -1323,6 +1373,108 @@ int demon_set_weights_blob_device(demon_ctx *c, const void *dblob, int64_t nfloa
     HIP_TRY(c, hipMemcpy(host.data(), dblob, sizeof(float) * (size_t)nfloats, hipMemcpyDeviceToHost));
     return demon_set_weights_blob(c, host.data(), nfloats);
 }
+
+// ---- multi-GPU: RCCL through the C ABI ---------------------------------------------------------------------
+// One process per GPU.  The path shards by image pair with no data-path collective; the one
+// collective is the broadcast of the weights at start-up.  librccl.so is loaded on first use (dlopen), so single-GPU
+// users of libdemon_hip.so have no RCCL link dependency; rccl.h supplies types and prototypes only.
+}  // extern "C"
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+static_assert(sizeof(ncclUniqueId) == DEMON_COMM_ID_BYTES, "include/demon_hip.h: DEMON_COMM_ID_BYTES must match ncclUniqueId");
+
+RcclApi &rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) { api.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return; }
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+        api.Broadcast = (decltype(api.Broadcast))dlsym(api.lib, "ncclBroadcast");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Broadcast) api.err = "librccl.so lacks the nccl* entry points";
+    });
+    return api;
+}
+int rccl_fail(demon_ctx *c, const char *what, int rc)
+{
+    RcclApi &r = rccl();
+    std::string msg = std::string(what) + ": " + (rc && r.GetErrorString ? r.GetErrorString((ncclResult_t)rc) : r.err.c_str());
+    return fail(c, DEMON_ERR_HIP, msg);
+}
+}  // namespace
+extern "C" {
+
+int demon_comm_get_unique_id(char *id)
+{
+    RcclApi &r = rccl();
+    if (!id) return fail(nullptr, DEMON_ERR_INVALID, "null id");
+    if (!r.err.empty()) return rccl_fail(nullptr, "rccl", 0);
+    ncclUniqueId u;
+    memset(&u, 0, sizeof u);
+    int rc = r.GetUniqueId(&u);
+    if (rc) return rccl_fail(nullptr, "ncclGetUniqueId", rc);
+    memcpy(id, u.internal, DEMON_COMM_ID_BYTES);
+    return DEMON_OK;
+}
+
+int demon_comm_init_rank(void **nccl_comm, int nranks, const char *id, int rank, int device)
+{
+    RcclApi &r = rccl();
+    if (!nccl_comm || !id || nranks < 1 || rank < 0 || rank >= nranks) return fail(nullptr, DEMON_ERR_INVALID, "bad argument");
+    *nccl_comm = nullptr;
+    if (!r.err.empty()) return rccl_fail(nullptr, "rccl", 0);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, DEMON_ERR_HIP, "hipSetDevice failed");
+    ncclUniqueId u;
+    memcpy(u.internal, id, DEMON_COMM_ID_BYTES);
+    int rc = r.CommInitRank((ncclComm_t *)nccl_comm, nranks, u, rank);
+    if (rc) return rccl_fail(nullptr, "ncclCommInitRank", rc);
+    return DEMON_OK;
+}
+
+int demon_comm_destroy(void *nccl_comm)
+{
+    RcclApi &r = rccl();
+    if (!nccl_comm) return DEMON_OK;
+    if (!r.err.empty()) return rccl_fail(nullptr, "rccl", 0);
+    int rc = r.CommDestroy((ncclComm_t)nccl_comm);
+    return rc ? rccl_fail(nullptr, "ncclCommDestroy", rc) : DEMON_OK;
+}
+
+// One ncclBroadcast of the packed weight slab (device to device over xGMI; no host staging, no repacking on the receivers:
+// every rank built the same layer table, so the slab layout is identical).  The root must have all weights set.
+int demon_broadcast_weights(demon_ctx *c, void *nccl_comm, int root, int rank)
+{
+    if (!c || !nccl_comm) return fail(c, DEMON_ERR_INVALID, "null argument");
+    if (!c->w_slab) return fail(c, DEMON_ERR_INVALID, "context has no networks (demon_create_ops)");
+    RcclApi &r = rccl();
+    if (!r.err.empty()) return rccl_fail(c, "rccl", 0);
+    std::string missing;
+    if (rank == root && !weights_ready(c, &missing)) return fail(c, DEMON_ERR_NOT_READY, "root rank: weights not set for layer " + missing);
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = r.Broadcast(c->w_slab, c->w_slab, c->w_slab_floats, ncclFloat32, root, (ncclComm_t)nccl_comm, c->stream);
+    if (rc) return rccl_fail(c, "ncclBroadcast", rc);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto &L : c->layers) L->have_kernel = L->have_bias = true;
+    return DEMON_OK;
+}
+
+int64_t demon_weights_slab_bytes(const demon_ctx *c) { return c ? (int64_t)(c->w_slab_floats * sizeof(float)) : 0; }
 
 int demon_set_option(demon_ctx *c, const char *key, int value)
 {
@@ -1545,19 +1697,26 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
     if (r) return r;
     if (repeats < 1 || !rec || !count) return fail(c, DEMON_ERR_INVALID, "bad arguments");
     hipSetDevice(c->device);
+    // exactly the steps a default forward pass launches (run_steps, mode 0): of the k x 1 / 1 x k pairs either the fused step or
+    // the two layer steps, never both; the image-feature cache steps only exist with reuse_image_features
     std::vector<const Step *> seq;
-    for (auto &s : c->net_boot) seq.push_back(&s);
+    auto active = [c](const Step &s) {
+        return s.image_only < 2 && !((s.pair == 1 && !c->opt_fused_pairs) || (s.pair == 2 && c->opt_fused_pairs));
+    };
+    for (auto &s : c->net_boot) if (active(s)) seq.push_back(&s);
     for (int i = 0; i < iterations; ++i)
-        for (auto &s : c->net_iter)
-            if (s.image_only < 2 && !((s.pair == 1 && !c->opt_fused_pairs) || (s.pair == 2 && c->opt_fused_pairs))) seq.push_back(&s);
-    for (auto &s : c->net_refine) seq.push_back(&s);
+        for (auto &s : c->net_iter) if (active(s)) seq.push_back(&s);
+    for (auto &s : c->net_refine) if (active(s)) seq.push_back(&s);
+    std::vector<std::string> tags(seq.size());
     std::vector<hipEvent_t> ev(2 * seq.size());
     for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
     std::vector<double> ms(seq.size(), 0.0);
     for (int rep = 0; rep < repeats + 1; ++rep) {  // first pass = warm-up
         for (size_t i = 0; i < seq.size(); ++i) {
             HIP_TRY(c, hipEventRecord(ev[2 * i], c->stream));
+            g_last_kernel = nullptr;
             seq[i]->fn(n, c->stream);
+            tags[i] = g_last_kernel ? g_last_kernel : "";
             HIP_TRY(c, hipEventRecord(ev[2 * i + 1], c->stream));
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1573,7 +1732,7 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
     for (size_t i = 0; i < seq.size() && (int)i < cap; ++i) {
         memset(&rec[i], 0, sizeof rec[i]);
         strncpy(rec[i].name, seq[i]->name.c_str(), sizeof rec[i].name - 1);
-        strncpy(rec[i].kernel, seq[i]->kernel.c_str(), sizeof rec[i].kernel - 1);
+        strncpy(rec[i].kernel, !tags[i].empty() ? tags[i].c_str() : seq[i]->kernel.c_str(), sizeof rec[i].kernel - 1);
         rec[i].flops = seq[i]->flops_per_sample * n;
         rec[i].bytes = seq[i]->bytes_per_sample * n + seq[i]->bytes_fixed;
         rec[i].ms = (float)(ms[i] / repeats);

@@ -1,6 +1,16 @@
-"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in CPU
-tests).  The path shards by image pair with no data-path collective; the only
-collective is one broadcast of the flat weight blob at start-up."""
+"""Multi-GPU plumbing: one process per GPU.  The path shards by image pair with no data-path collective
+(SURVEY.md section 8e); the only collective is one broadcast of the weights at start-up.
+
+Two broadcast routes:
+  * "rccl"  (GPU, default): an RCCL communicator created THROUGH THE C ABI (demon_comm_*: ncclGetUniqueId /
+            ncclCommInitRank) and ONE ncclBroadcast of the packed, device-resident weight slab (demon_broadcast_weights).
+            torch.distributed is used only to ship the 128-byte unique id between the ranks (any other channel works:
+            `exchange` is a callable), so a ctypes / C caller can bring up N GPUs without torch.
+  * "torch" (CPU tests with gloo, or two ranks sharing one GPU, which RCCL refuses): torch.distributed.broadcast of the
+            TF-layout float blob, then demon_set_weights_blob(_device) on every rank.
+"""
+import ctypes
+
 import numpy as np
 
 
@@ -11,9 +21,48 @@ def shard_range(global_batch, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def torch_exchange(payload, src=0):
+    """ships a small bytes object from rank `src` to every rank over the initialised torch.distributed group"""
+    import torch.distributed as dist
+    box = [payload if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+class NativeComm:
+    """RCCL communicator owned through the C ABI (include/demon_hip.h: demon_comm_*).  `exchange(bytes_or_None) -> bytes`
+    ships rank 0's unique id to everybody (default: torch.distributed)."""
+
+    def __init__(self, rank, world, device, exchange=torch_exchange):
+        from . import _lib
+        self.lib = _lib.load()
+        self.rank, self.world, self.device = rank, world, device
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            self._check(self.lib.demon_comm_get_unique_id(buf), "demon_comm_get_unique_id")
+        uid = exchange(buf.raw if rank == 0 else None) if world > 1 else buf.raw
+        self.handle = ctypes.c_void_p()
+        self._check(self.lib.demon_comm_init_rank(ctypes.byref(self.handle), world, uid, rank, device), "demon_comm_init_rank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.demon_last_error(None).decode()))
+
+    def broadcast_weights(self, ctx, root=0):
+        """one ncclBroadcast of ctx's packed weight slab from `root`; every rank must call it"""
+        rc = self.lib.demon_broadcast_weights(ctx.h, self.handle, root, self.rank)
+        if rc != 0:
+            raise RuntimeError("demon_broadcast_weights failed (%d): %s" % (rc, self.lib.demon_last_error(ctx.h).decode()))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.demon_comm_destroy(self.handle)
+            self.handle = None
+
+
 def broadcast_blob(blob, nfloats, device, src=0):
     """blob: 1-D float32 numpy array on `src`, ignored elsewhere.  Returns a torch tensor on `device`
-    holding the blob on every rank (one ncclBroadcast / RCCL over xGMI when device is a GPU)."""
+    holding the blob on every rank (torch.distributed.broadcast: gloo on CPU tensors, RCCL on GPU tensors)."""
     import torch
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size() > 1:
@@ -26,6 +75,40 @@ def broadcast_blob(blob, nfloats, device, src=0):
         dist.broadcast(t, src=src)
         return t
     return torch.from_numpy(np.ascontiguousarray(blob, np.float32)).to(device)
+
+
+def distribute_weights(ctx, host_weights, rank, world, route="rccl", comm=None):
+    """Puts rank 0's weights (dict tf name -> array; None on the other ranks) on every rank's context.
+    Returns (seconds spent in the broadcast, route description)."""
+    import time
+    from . import weights as W
+    if route == "rccl":
+        own = comm is None
+        if own:
+            comm = NativeComm(rank, world, ctx.device)
+        if rank == 0:
+            ctx.set_weights(host_weights)      # TF layouts -> packed slab, on the root only
+        t0 = time.perf_counter()
+        comm.broadcast_weights(ctx, 0)         # synchronous on the context's stream
+        dt = time.perf_counter() - t0
+        if own:
+            comm.close()
+        return dt, "one ncclBroadcast of the packed %.0f MB weight slab through the C ABI (demon_broadcast_weights)" % (
+            ctx.lib.demon_weights_slab_bytes(ctx.h) / 1e6)
+    import torch
+    order = ctx.variables()
+    blob = W.weights_to_blob(host_weights, order) if rank == 0 else None
+    on_gpu = route == "torch-gpu"
+    t0 = time.perf_counter()
+    t = broadcast_blob(blob, ctx.blob_size(), torch.device("cuda", ctx.device) if on_gpu else "cpu")
+    if on_gpu:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if on_gpu:
+        ctx.set_weights_blob_device(t.data_ptr(), t.numel())
+    else:
+        ctx.set_weights_blob(t.numpy())
+    return dt, "torch.distributed.broadcast of the %.0f MB TF-layout blob (%s)" % (4e-6 * ctx.blob_size(), route)
 
 
 def max_over_ranks(value, device):

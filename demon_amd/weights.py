@@ -137,6 +137,22 @@ def variable_shapes(height=192, width=256, version=1):
     return out
 
 
+def blob_order(height=192, width=256, version=1):
+    """[(variable name, shape)] in the order of the flat weight blob = the order libdemon_hip.so creates its variables
+    (demon_variable_info / DemonContext.variables(); a GPU test holds the two lists equal, element by element)."""
+    return list(variable_shapes(height, width, version).items())
+
+
+def blob_to_weights(blob, order):
+    """inverse of weights_to_blob: views into `blob`"""
+    w, off = {}, 0
+    for name, shape in order:
+        cnt = int(np.prod(shape))
+        w[name] = blob[off:off + cnt].reshape(shape)
+        off += cnt
+    return w
+
+
 _LINEAR = ("predict_flow5/conv2", "predict_flow2/conv2", "predict_depthnormal2/conv2", "predict_depth0/conv2",
            "upsample_flow5to4/upconv", "motion_fc3")
 

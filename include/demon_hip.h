@@ -137,7 +137,8 @@ int demon_time_full(demon_ctx *ctx, int n, int iterations, int steps, float *tot
 /* ---- per-launch profile (hip events around every kernel launch of one full pass, eager) ---------- */
 typedef struct demon_launch_record {
     char name[64];     /* e.g. "netFlow1/conv1y" */
-    char kernel[32];   /* kernel family, e.g. "conv_mfma" */
+    char kernel[32];   /* the kernel that ran: "conv_mfma<128x32>+splitk" (= conv_mfma_kernel<128, 32, ..> followed by the split-K
+                          reduce), "conv_patch<64x128,t5>", "deconv4<32x128>", "conv_pair", "conv_small", "warp2d", ... */
     double flops;      /* algorithmic 2*MAC of this launch (0 for non conv ops) */
     double bytes;      /* algorithmic bytes read + written */
     float ms;
@@ -173,6 +174,24 @@ int demon_op_depth_to_normals(demon_ctx *ctx, float *out, const float *depth, co
 /* pointwise_l2_loss of v2/losses.py:33-54 (NCHW): mean over pixels of sqrt(sum_c replace_nonfinite(inp - gt)^2 + epsilon) */
 int demon_op_pointwise_l2_loss(demon_ctx *ctx, float *loss, const float *inp, const float *gt, int n, int c, int h, int w,
                                float epsilon);
+
+/* ---- multi-GPU: one process per GPU, RCCL through the C ABI ------------------------------------------
+ * image pairs shard across ranks with no data-path collective; the only collective is one
+ * broadcast of the weights at start-up (the reference has no multi-GPU inference path; tf.train.Saver.restore,
+ * examples/example.py:82-83, is what each process would otherwise repeat from disk).
+ *   demon_comm_get_unique_id : ncclGetUniqueId -- call on ONE rank, ship the 128 bytes to the others by any means
+ *                              (MPI, a file, torch.distributed's store ...)
+ *   demon_comm_init_rank     : ncclCommInitRank on `device`; *nccl_comm is a plain ncclComm_t, usable with rccl.h directly
+ *   demon_broadcast_weights  : ONE ncclBroadcast (float32) of the packed device-resident weight slab from `root` on the
+ *                              context's stream, then marks every variable as set; `nccl_comm` may be any ncclComm_t whose
+ *                              rank `rank` is this process.  Collective: every rank of the communicator must call it.
+ * librccl.so is dlopen'ed on first use; without it these return DEMON_ERR_HIP and nothing else is affected. */
+#define DEMON_COMM_ID_BYTES 128
+int demon_comm_get_unique_id(char *id /* [DEMON_COMM_ID_BYTES] */);
+int demon_comm_init_rank(void **nccl_comm, int nranks, const char *id /* [DEMON_COMM_ID_BYTES] */, int rank, int device);
+int demon_comm_destroy(void *nccl_comm);
+int demon_broadcast_weights(demon_ctx *ctx, void *nccl_comm, int root, int rank);
+int64_t demon_weights_slab_bytes(const demon_ctx *ctx);
 
 /* ---- layer-level entry points (host buffers; TF weight layouts) -------------------------------------
  * Replace the tf.layers calls of helpers.py:85-94 / :128-153 (conv2d on a zero padded input),

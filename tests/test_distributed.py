@@ -30,16 +30,12 @@ def _worker(rank, world, port, tmpdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        order = sorted(W.variable_shapes().items())
+        order = W.blob_order()          # the library's variable order (= DemonContext.variables() on a GPU box)
         nfloats = sum(int(np.prod(s)) for _, s in order)
+        assert nfloats == 45753883
         blob = W.weights_to_blob(W.synthetic_weights(seed=1), order) if rank == 0 else None
         t = D.broadcast_blob(blob, nfloats, "cpu").numpy()
-        # rebuild the dict from the broadcast blob
-        w, off = {}, 0
-        for name, shape in order:
-            cnt = int(np.prod(shape))
-            w[name] = t[off:off + cnt].reshape(shape)
-            off += cnt
+        w = W.blob_to_weights(t, order)  # rebuild the dict from the broadcast blob
         pair, img2_2 = make_inputs(3, seed=42)           # global batch 3 over 2 ranks: shards of 2 and 1
         lo, hi = D.shard_range(3, rank, world)
         out = net_ref.DemonRef(w).bootstrap(pair[lo:hi], img2_2[lo:hi])
@@ -79,3 +75,82 @@ def test_two_process_broadcast_and_sharding(tmp_path):
         got = np.concatenate([r0[k], r1[k]], 0)
         assert got.shape == want[k].shape
         assert np.abs(got - want[k]).sum() / np.abs(want[k]).sum() < 1e-5
+
+
+# ---- GPU: the real contexts behind the N > 1 path, as far as one GPU allows ---------------------------------------------
+def _gpu_worker(rank, world, port, tmpdir):
+    """two ranks SHARING GPU 0 (RCCL refuses two ranks on one device, so the collective runs over gloo; everything else is
+    the production path: one DemonContext per rank, weights from the broadcast blob, per-rank shard, max-over-ranks)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from demon_amd import DemonContext, weights as W
+    from demon_amd import distributed as D
+    from conftest import make_inputs
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gb = 5
+        lo, hi = D.shard_range(gb, rank, world)           # shards of 3 and 2
+        ctx = DemonContext(0, hi - lo, 192, 256)
+        host = W.synthetic_weights(seed=1) if rank == 0 else None
+        dt, desc = D.distribute_weights(ctx, host, rank, world, route="torch")
+        assert "gloo" in desc or "torch" in desc
+        pair, img2_2 = make_inputs(gb, seed=77)
+        out = ctx.full(pair[lo:hi], img2_2[lo:hi], iterations=1)
+        np.savez(os.path.join(tmpdir, "gpu_rank%d.npz" % rank), lo=lo, hi=hi, **out)
+        assert D.max_over_ranks(10.0 * (rank + 1), "cpu") == 10.0 * world
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_sharded_equals_unsharded(tmp_path):
+    import torch.multiprocessing as mp
+    from demon_amd import DemonContext, weights as W
+    from conftest import make_inputs
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "gpu_rank0.npz"), np.load(tmp_path / "gpu_rank1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 3, 3, 5)
+    pair, img2_2 = make_inputs(5, seed=77)
+    ctx = DemonContext(0, 5, 192, 256)
+    try:
+        ctx.set_weights(W.synthetic_weights(seed=1))
+        want = ctx.full(pair, img2_2, iterations=1)
+    finally:
+        ctx.close()
+    for k in ("predict_flow2", "predict_depth2", "predict_normal2", "predict_rotation", "predict_translation", "predict_depth0"):
+        got = np.concatenate([r0[k], r1[k]], 0)
+        assert got.shape == want[k].shape and np.isfinite(got).all()
+        # same kernels, different batch size per launch (3 / 2 / 5): tile plans and split-K may differ -> summation order only
+        assert np.abs(got - want[k]).sum() / np.abs(want[k]).sum() < 1e-4, k
+
+
+@pytest.mark.gpu
+def test_rccl_broadcast_through_the_c_abi_single_rank():
+    """demon_comm_get_unique_id / demon_comm_init_rank / demon_broadcast_weights / demon_comm_destroy with a 1-rank RCCL
+    communicator (all one GPU allows): the packed weight slab is broadcast in place and the outputs are unchanged; a root
+    without weights is refused before the collective starts"""
+    from demon_amd import DemonContext, weights as W
+    from demon_amd import distributed as D
+    from conftest import make_inputs
+    pair, img2_2 = make_inputs(2, seed=78)
+    ctx = DemonContext(0, 2, 192, 256)
+    comm = D.NativeComm(0, 1, 0)
+    try:
+        with pytest.raises(RuntimeError, match="weights not set"):
+            comm.broadcast_weights(ctx, 0)
+        ctx.set_weights(W.synthetic_weights(seed=1))
+        before = ctx.bootstrap(pair, img2_2)
+        assert ctx.lib.demon_weights_slab_bytes(ctx.h) >= 4 * ctx.blob_size()
+        comm.broadcast_weights(ctx, 0)
+        after = ctx.bootstrap(pair, img2_2)
+        for k in before:
+            np.testing.assert_array_equal(before[k], after[k])
+    finally:
+        comm.close()
+        ctx.close()

@@ -31,6 +31,7 @@ def test_variable_table_matches_library(gpu_ctx):
     from demon_amd import weights
     lib_vars = dict(gpu_ctx.variables())
     assert lib_vars == weights.variable_shapes()
+    assert gpu_ctx.variables() == weights.blob_order()   # same ORDER too: it is the layout of the flat weight blob
     assert gpu_ctx.blob_size() == 45753883
 
 

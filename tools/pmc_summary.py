@@ -9,18 +9,45 @@ their bytes (MI355X_MICROARCH.md, section HBM): the read side is doubled here, t
 """
 import collections
 import csv
+import glob
 import json
 import os
+import re
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def kernel_tag(name):
+    """rocprofv3 kernel name -> the tag demon_profile_full / bench.py use for the same template instance"""
+    m = re.search(r"conv_mfma_kernel<(\d+), (\d+)", name)
+    if m:
+        return "conv_mfma<%sx%s>" % m.groups()
+    m = re.search(r"conv_patch_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        bm, wm, wn, tm, tn, taps = map(int, m.groups())
+        return "conv_patch<%dx%d,t%d>" % (bm, wn * tn * (16 if bm == 16 else 32), taps)
+    m = re.search(r"deconv4_kernel<(\d+), (\d+), (\d+)", name)
+    if m:
+        bm, wm, wn = map(int, m.groups())
+        return "deconv4<%dx%d>" % (bm, wn * 32)
+    m = re.search(r"demon::(\w+?)_kernel", name)
+    return m.group(1) if m else name.split("(")[0]
 
 
 def load(d):
+    """family -> counter -> values, and the same per kernel tag; `d` holds the csv of one rocprofv3 --pmc pass"""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    with open(os.path.join(d, "p_counter_collection.csv")) as f:
+    path = os.path.join(d, "p_counter_collection.csv")
+    if not os.path.exists(path):
+        found = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        path = found[0] if found else path
+    with open(path) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
             fam = "conv" if any(k in name for k in ("conv_mfma_kernel", "conv_patch_kernel", "deconv4_kernel", "conv_pair_kernel")) else name.split("(")[0].replace("demon::", "")
             agg[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg["kernel:" + kernel_tag(name)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
 
@@ -43,9 +70,14 @@ def main():
             act = sum(m["GRBM_GUI_ACTIVE"]) / 8.0  # summed over the 8 XCDs
             e["mfma_busy_frac"] = busy / (act * 1024.0)  # 256 CUs x 4 SIMDs
         out[fam] = e
+    for e in out.values():
+        if "fetch_bytes_per_launch_corrected_x2" in e:
+            e["hbm_traffic_bytes_per_launch"] = e["fetch_bytes_per_launch_corrected_x2"] + e.get("write_bytes_per_launch_reported", 0.0)
     c = out.get("conv", {})
-    if "fetch_bytes_per_launch_corrected_x2" in c:
-        c["hbm_traffic_bytes_per_launch"] = c["fetch_bytes_per_launch_corrected_x2"] + c.get("write_bytes_per_launch_reported", 0.0)
+    # per template instance (the tags of demon_profile_full) under "kernels"; the kernel sources these counters were measured on
+    out["kernels"] = {k[len("kernel:"):]: out.pop(k) for k in [k for k in out if k.startswith("kernel:")]}
+    from demon_amd import build as hip_build
+    out["csrc_sha"] = hip_build.csrc_sha()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", tag + "_pmc_summary.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
