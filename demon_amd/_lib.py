@@ -33,6 +33,7 @@ SIGNATURES = {
     "demon_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "demon_create_v2": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "demon_create_ops": (_I, [ctypes.POINTER(_P), _I]),
+    "demon_debug_timeline": (_I, [_P, ctypes.c_char_p, _I, ctypes.POINTER(ctypes.c_uint64), _I, c_int_p, c_float_p, ctypes.c_char_p, _I]),
     "demon_comm_get_unique_id": (_I, [ctypes.c_char_p]),
     "demon_comm_init_rank": (_I, [ctypes.POINTER(_P), _I, ctypes.c_char_p, _I, _I]),
     "demon_comm_destroy": (_I, [_P]),

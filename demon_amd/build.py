@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdemon_hip.so")
-SOURCES = ["demon_api.hip", "conv_mfma.hip", "conv_patch.hip", "conv_small.hip", "conv_pair.hip", "ops.hip"]
+SOURCES = ["demon_api.hip", "conv_mfma.hip", "conv_patch.hip", "conv_small.hip", "conv_pair.hip", "conv_stream.hip", "ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -36,17 +36,20 @@ def _needs_build(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), tag=""):
+    """tag / extra_flags: diagnostic variants (e.g. tag="tl", extra_flags=["-DDEMON_TIMELINE"] -> libdemon_hip_tl.so with its own
+    object files); the product library is the untagged build"""
     hipcc = _hipcc()
+    out = OUT if not tag else OUT.replace(".so", "_%s.so" % tag)
     headers = [os.path.join(CSRC, "internal.h"), os.path.join(HERE, "..", "include", "demon_hip.h")]
     objs = []
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", (".%s.o" % tag) if tag else ".o"))
         objs.append(o)
         if force or _needs_build(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -56,10 +59,15 @@ def build(force=False, verbose=False):
     if jobs:
         with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _needs_build(OUT, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
-    return OUT
+    if jobs or force or _needs_build(out, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--dbg" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_STREAM_DBG"], tag="dbg"))
+    elif "--timeline" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_TIMELINE"], tag="tl"))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     constexpr int APER = (BK + AROWS - 1) / AROWS;
     static_assert(NT % BN == 0 && BK % BROWS == 0, "bad B staging shape");
 
+    TlScope tl(a.tl);
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
         store_tiles(0);
     }
     __syncthreads();
+    tl.mark(1);
     // steps in pairs so that the table double buffer is indexed statically: during an even step s the gathers
     // of step s+1 read kentB while kentA is refilled for step s+2, and vice versa during odd steps
     int s = 0;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
         ++s;
     }
     if (nsteps > 0) kstep(s & 1, 0, kentA, kentB, std::false_type{});
+    tl.mark(2);
 
     if (a.ksplit > 1) {
         // split-K: raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     static_assert((M16 ? (WM == 1 && TM == 1) : BM == WM * TM * 32) && CKS % KG == 0, "bad tile");
     using AccT = typename std::conditional<M16, floatx4, floatx16>::type;
 
+    TlScope tl(a.tl);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                           // [2][KD][BM]
     float *Ps = smem + 2 * KD * BM;             // [2][patch_floats]
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
         store_tiles(pregA, aregA, 0, okmask_of(p0s));
     }
     __syncthreads();
+    tl.mark(1);
     // during step s (buffer s&1): MFMAs on step s, loads of step s+2 into the set that step s freed, then the
     // set holding step s+1 goes to LDS buffer (s+1)&1.  Pairs of steps keep the set indices static.
     int s = 0;
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
         ++s;
     }
     if (nsteps > 0) kstep(s & 1, 0, pregA, aregA, std::false_type{});
+    tl.mark(2);
 
     // ---- epilogue
     const int opy = cls >> 1, opx = cls & 1;
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(64 * WM * WN) void deconv4_kernel(PatchArgs a)
     constexpr int APER = (A4 + NT - 1) / NT;
     static_assert(BM == WM * 32, "bad tile");
 
+    TlScope tl(a.tl);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                            // [2][4][KD][BM]
     float *Ps = smem + 2 * 4 * KD * BM;          // [2][patch_floats]
@@ -485,6 +489,7 @@ __global__ __launch_bounds__(64 * WM * WN) void deconv4_kernel(PatchArgs a)
         store_tiles(pregA, aregA, 0, okmask_of(p0s));
     }
     __syncthreads();
+    tl.mark(1);
     int s = 0;
     for (; s + 2 < nsteps; s += 2) {
         kstep(0, phys(s + 2), pregA, aregA, std::true_type{});
@@ -501,6 +506,7 @@ __global__ __launch_bounds__(64 * WM * WN) void deconv4_kernel(PatchArgs a)
         ++s;
     }
     if (nsteps > 0) kstep(s & 1, 0, pregA, aregA, std::false_type{});
+    tl.mark(2);
 
     // ---- epilogue: lane = input pixel (y, x) of the tile
     const int y = ty * a.TH + ppy, x = tx * a.TW + ppx, n = n0 + pg;

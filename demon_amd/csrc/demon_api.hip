@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <array>
 #include <functional>
 #include <mutex>
@@ -30,6 +31,7 @@ namespace {
 thread_local std::string g_create_error;
 // kernel family the last run_layer / run_pair call launched ("conv_mfma", "conv_patch", "deconv4", "conv_small", "conv_pair",
 // with "+splitk" when a split-K reduce launch follows); demon_profile_full reads it to attribute time per kernel
+unsigned long long *g_timeline_dev = nullptr;  // diagnostic build (demon_debug_timeline): where the kernels write their records
 thread_local const char *g_last_kernel = nullptr;
 thread_local char g_kernel_tag[32];
 void set_kernel_tag(const char *family, int bm, int bn, int taps, bool splitk)
@@ -49,12 +51,20 @@ struct Layer {
     int K = 0, Kpad = 0, Krows = 0, Mpad = 0, ncls = 1;
     float *d_wp = nullptr, *d_bias = nullptr;
     KEntry *d_ktab = nullptr;
+    // conv_stream.hip (Cin % 16 == 0): the same weights in MFMA fragment order, refreshed from d_wp whenever that changes, and
+    // the page of zeros that taps outside the image read
+    float *d_wf = nullptr;
+    const float *zero = nullptr;
+    mutable bool wf_dirty = true;
     bool have_kernel = false, have_bias = false;
     std::vector<int64_t> kernel_dims;  // TF layout
     int force_tile = -1, force_split = 0;  // tuning override (demon_bench_layer)
     // autotuned choice per batch size: kind 0 = im2col kernel (tile, ksplit), 1 = patch kernel (patch tile)
     struct Tuned { int kind, tile, ksplit; };
     std::map<int, Tuned> tuned;
+    int ntaps() const { return kind == DECONV ? 4 : (kind == DENSE ? 1 : kh * kw); }
+    bool stream_ok() const { return d_wf != nullptr && zero != nullptr; }
+    static bool stream_shape_ok(Kind kind, int Cin, int kh, int kw) { return Cin % 16 == 0 && (kind != CONV || kh * kw <= 9); }
 };
 
 struct Step {
@@ -112,6 +122,7 @@ struct demon_ctx {
     // demon_broadcast_weights is a single RCCL broadcast of device-resident, already packed data
     float *w_slab = nullptr;
     size_t w_slab_floats = 0;
+    float *d_zero = nullptr;  // shared zero page of the conv_stream layers
 };
 
 namespace {
@@ -223,6 +234,15 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
     L->Krows = L->Kpad + 16;  // 16 zero rows of slack: the patch kernel's last channel chunk may read past K
     if (!L->d_ktab) return false;
     if (hipMemcpy(L->d_ktab, tab.data(), tab.size() * sizeof(KEntry), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (Layer::stream_shape_ok(L->kind, L->Cin, L->kh, L->kw) && !getenv("DEMON_NO_STREAM")) {
+        L->d_wf = dev_alloc(c, sizeof(float) * (size_t)L->ncls * L->K * L->Mpad);
+        L->wf_dirty = true;
+        if (alloc_weights) {  // stand-alone layer (demon_op_*, demon_bench_layer): its own zero page
+            const size_t zf = (size_t)(L->Cin + 2) * H * W;
+            float *z = dev_alloc(c, sizeof(float) * zf);
+            if (z && hipMemset(z, 0, sizeof(float) * zf) == hipSuccess) L->zero = z;
+        }
+    }
     if (!alloc_weights) return true;  // network layers: alloc_weight_slab() places d_wp / d_bias once all layers exist
     L->d_wp = dev_alloc(c, sizeof(float) * (size_t)L->ncls * L->Krows * L->Mpad);
     L->d_bias = dev_alloc(c, sizeof(float) * L->Mpad);
@@ -241,6 +261,14 @@ bool alloc_weight_slab(demon_ctx *c)
     c->w_slab = dev_alloc(c, sizeof(float) * total);
     if (!c->w_slab || hipMemset(c->w_slab, 0, sizeof(float) * total) != hipSuccess) return false;
     c->w_slab_floats = total;
+    size_t zf = 0;
+    for (auto &L : c->layers)
+        if (L->d_wf) zf = std::max(zf, (size_t)(L->Cin + 2) * L->in.H * L->in.W);
+    if (zf) {
+        c->d_zero = dev_alloc(c, sizeof(float) * zf);
+        if (!c->d_zero || hipMemset(c->d_zero, 0, sizeof(float) * zf) != hipSuccess) return false;
+        for (auto &L : c->layers) if (L->d_wf) L->zero = c->d_zero;
+    }
     size_t off = 0;
     for (auto &L : c->layers) {
         L->d_wp = c->w_slab + off;
@@ -275,6 +303,7 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
     }
     HIP_TRY(c, hipMemcpy(L->d_wp, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
     L->have_kernel = true;
+    L->wf_dirty = true;
     return DEMON_OK;
 }
 
@@ -303,6 +332,7 @@ void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
     a.act = L->act;
     a.cls_w_stride = (long)L->Krows * L->Mpad;
     a.ksplit = 1;
+    a.tl = g_timeline_dev;
     static const int xcd_order = getenv("DEMON_XCD_ORDER") ? atoi(getenv("DEMON_XCD_ORDER")) : 1;
     a.xcd = xcd_order;
     if (L->kind == Layer::DECONV) {
@@ -382,7 +412,7 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
     a.Hp = Hp; a.Wp = Wp; a.sh = sh; a.sw = sw;
     a.Cout = L->Cout; a.Mpad = L->Mpad; a.cls_w_stride = ca.cls_w_stride;
     a.Ho = ca.Ho; a.Wo = ca.Wo; a.out_n_stride = ca.out_n_stride; a.osy = ca.osy; a.osx = ca.osx;
-    a.act = L->act; a.nsteps_total = chunks; a.xcd = ca.xcd;
+    a.act = L->act; a.nsteps_total = chunks; a.xcd = ca.xcd; a.tl = ca.tl;
     const bool fused_classes = patch_tile_is_dc4(pp.tile);
     {
         // LDS layout of the patch: row pitch PWL >= PW and plane stride PS >= PH * PWL chosen so that the 32 lanes of one
@@ -497,6 +527,50 @@ void run_small(const Layer *L, const ConvArgs &a, hipStream_t s)
     g_last_kernel = "conv_small";
 }
 
+// d_wp -> fragment order for conv_stream.hip; outside graph capture for network layers (prepare_stream_weights), on the spot
+// for stand-alone layers
+void refresh_stream_weights(const Layer *L, hipStream_t s)
+{
+    if (!L->d_wf || !L->wf_dirty) return;
+    launch_stream_repack(L->d_wf, L->d_wp, L->ncls, L->K, L->Mpad, (long)L->Krows * L->Mpad, s);
+    L->wf_dirty = false;
+}
+
+void run_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
+{
+    refresh_stream_weights(L, s);
+    StreamArgs sa;
+    sa.c = a;
+    sa.wf = L->d_wf;
+    sa.zero = L->zero;
+    sa.dbg = getenv("DEMON_STREAM_DBG") ? atoi(getenv("DEMON_STREAM_DBG")) : 0;
+    sa.cls_wf_stride = (long)L->K * L->Mpad;
+    sa.ntaps = L->ntaps();
+    sa.csteps = L->Cin / 16;
+    sa.nsteps = sa.ntaps * sa.csteps;
+    memset(sa.tapdy, 0, sizeof sa.tapdy);
+    memset(sa.tapdx, 0, sizeof sa.tapdx);
+    if (L->kind == Layer::DECONV) {
+        static const int tap_d[2][2] = {{0, -1}, {1, 0}};  // as plan_layer's K table
+        for (int cls = 0; cls < 4; ++cls)
+            for (int ty = 0; ty < 2; ++ty)
+                for (int tx = 0; tx < 2; ++tx) {
+                    sa.tapdy[cls][ty * 2 + tx] = tap_d[cls >> 1][ty];
+                    sa.tapdx[cls][ty * 2 + tx] = tap_d[cls & 1][tx];
+                }
+    } else if (L->kind == Layer::CONV) {
+        for (int ta = 0; ta < L->kh; ++ta)
+            for (int tb = 0; tb < L->kw; ++tb) {
+                sa.tapdy[0][ta * L->kw + tb] = ta - L->ph;
+                sa.tapdx[0][ta * L->kw + tb] = tb - L->pw;
+            }
+    }
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > sa.nsteps) ksplit = sa.nsteps;
+    launch_conv_stream(sa, variant, ksplit, L->ncls, s);
+    set_kernel_tag("conv_stream", stream_variant_bm(variant), stream_variant_bn(variant), 0, ksplit > 1);
+}
+
 void run_mfma(const ConvArgs &a, ConvPlan plan, int ncls, hipStream_t s)
 {
     launch_conv_mfma(a, plan, ncls, s);
@@ -518,6 +592,11 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
         if (sscanf(fp, "%d,%d,%d", &kind, &tile, &ks) == 3) {
             if (kind == 3) {
                 if (small_applies(L)) { run_small(L, a, s); return; }
+            } else if (kind == 4) {
+                if (L->stream_ok() && tile >= 0 && tile < STREAM_VARIANTS && L->Mpad % stream_variant_bm(tile) == 0) {
+                    run_stream(L, a, tile, clamp_split(ks), s);
+                    return;
+                }
             } else if (kind == 1) {
                 PatchPlan pp;
                 if (tile >= 0 && tile < PTILE_COUNT && plan_patch(L, n, ws, pp, tile)) {
@@ -539,6 +618,10 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 run_small(L, a, s);
                 return;
             }
+            if (t.kind == 4 && L->stream_ok() && L->Mpad % stream_variant_bm(t.tile) == 0) {
+                run_stream(L, a, t.tile, clamp_split(t.ksplit), s);
+                return;
+            }
             if (t.kind == 1) {
                 PatchPlan pp;
                 if (plan_patch(L, n, ws, pp, t.tile)) {
@@ -546,14 +629,18 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                     launch_patch_plan(L, pp, a, P, ws, s);
                     return;
                 }
-            } else {
+            } else if (t.kind == 0) {
                 run_mfma(a, ConvPlan{t.tile, clamp_split(t.ksplit)}, L->ncls, s);
                 return;
             }
         }
     }
+    if (L->force_tile >= 200) {  // demon_bench_layer: streaming kernel variant force_tile - 200
+        const int v = L->force_tile - 200;
+        if (L->stream_ok() && v < STREAM_VARIANTS && L->Mpad % stream_variant_bm(v) == 0) { run_stream(L, a, v, clamp_split(L->force_split), s); return; }
+    }
     if (L->force_tile < 0 && small_applies(L)) { run_small(L, a, s); return; }  // Cout <= 4 heads: VALU direct conv
-    if (L->force_tile < 0 || L->force_tile >= 100) {
+    if (L->force_tile < 0 || (L->force_tile >= 100 && L->force_tile < 200)) {
         PatchPlan pp;
         if (plan_patch(L, n, ws, pp, L->force_tile >= 100 ? L->force_tile - 100 : -1)) {
             if (L->force_split > 0) pp.a.ksplit = L->force_split;
@@ -602,6 +689,19 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
         }
     }
     if (small_applies(L)) cands.push_back({3, 0, 0});
+    if (L->stream_ok()) {
+        const int nsteps = L->K / 16;
+        for (int v = 0; v < STREAM_VARIANTS; ++v) {
+            if (L->Mpad % stream_variant_bm(v)) continue;
+            const long wgs = (long)(L->Mpad / stream_variant_bm(v)) * ((P + stream_variant_bn(v) - 1) / stream_variant_bn(v)) * L->ncls;
+            const long waves = wgs * stream_variant_waves(v);
+            for (int ks : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48}) {
+                if (ks > 1 && (ks > nsteps / 3 || (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
+                if (waves * ks < 512 || waves * ks > 16384) continue;  // at least half a wave per SIMD, at most 16
+                cands.push_back({4, v, ks});
+            }
+        }
+    }
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;
     float best = 1e30f;
@@ -1126,12 +1226,20 @@ int run_sequence(demon_ctx *c, int kind, int n, int iterations)
     return DEMON_OK;
 }
 
+// fragment-order copies of the weights (conv_stream.hip) follow every weight change; done here, before a sequence is captured
+void prepare_stream_weights(demon_ctx *c)
+{
+    for (auto &L : c->layers) refresh_stream_weights(L.get(), c->stream);
+}
+
 int check_batch(demon_ctx *c, int n)
 {
     if (!c) return DEMON_ERR_INVALID;
     if (n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "batch size out of range [1, max_batch]");
     std::string missing;
     if (!weights_ready(c, &missing)) return fail(c, DEMON_ERR_NOT_READY, "weights not set for layer " + missing);
+    hipSetDevice(c->device);
+    prepare_stream_weights(c);
     return DEMON_OK;
 }
 
@@ -1470,7 +1578,7 @@ int demon_broadcast_weights(demon_ctx *c, void *nccl_comm, int root, int rank)
     int rc = r.Broadcast(c->w_slab, c->w_slab, c->w_slab_floats, ncclFloat32, root, (ncclComm_t)nccl_comm, c->stream);
     if (rc) return rccl_fail(c, "ncclBroadcast", rc);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (auto &L : c->layers) L->have_kernel = L->have_bias = true;
+    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; }
     return DEMON_OK;
 }
 
@@ -1497,6 +1605,7 @@ int demon_autotune(demon_ctx *c, int n)
     hipSetDevice(c->device);
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);  // captured launches embed the old choices
     c->graphs.clear();
+    prepare_stream_weights(c);
     for (auto &L : c->layers) {
         int r = autotune_layer(c, L.get(), n);
         if (r) return fail(c, r, "autotune failed at layer " + L->name);
@@ -1522,15 +1631,16 @@ int demon_plan_get(const demon_ctx *c, int n, int layer_index, char *name, int n
 int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int tile, int ksplit)
 {
     if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
-    if (kind < 0 || kind > 3 || kind == 2 || tile < 0 || tile >= (kind == 1 ? (int)PTILE_COUNT : (int)TILE_COUNT) || ksplit < 0)
+    if (kind < 0 || kind > 4 || kind == 2 || tile < 0 || tile >= (kind == 1 ? (int)PTILE_COUNT : (kind == 4 ? (int)STREAM_VARIANTS : (int)TILE_COUNT)) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
             if (kind == 0 && L->Mpad % conv_tile_bm(tile)) return fail(c, DEMON_ERR_INVALID, "tile does not divide Cout");
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
+            if (kind == 4 && (!L->stream_ok() || L->Mpad % stream_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the streaming kernel does not apply to this layer");
             for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
             c->graphs.clear();
-            L->tuned[n] = Layer::Tuned{kind, tile, kind == 0 && ksplit < 1 ? 1 : ksplit};
+            L->tuned[n] = Layer::Tuned{kind, tile, (kind == 0 || kind == 4) && ksplit < 1 ? 1 : ksplit};
             return DEMON_OK;
         }
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown layer ") + layer_name);
@@ -1914,7 +2024,7 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
 int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw,
                       int tile, int ksplit, int iters, float *avg_ms, double *flops)
 {
-    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || tile >= 100 + PTILE_COUNT) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || tile >= 200 + STREAM_VARIANTS) return fail(c, DEMON_ERR_INVALID, "bad argument");
     hipSetDevice(c->device);
     demon_ctx scratch;
     scratch.device = c->device;
@@ -1966,6 +2076,52 @@ int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int
     }
     for (void *p : scratch.allocations) hipFree(p);
     return rc;
+}
+
+// Diagnostic: per-workgroup wall-clock records of ONE launch of a network layer (only in builds with -DDEMON_TIMELINE).
+int demon_debug_timeline(demon_ctx *c, const char *layer_name, int n, uint64_t *records, int cap, int *count, float *ms, char *kernel, int kernel_cap)
+{
+#ifndef DEMON_TIMELINE
+    (void)layer_name; (void)n; (void)records; (void)cap; (void)count; (void)ms; (void)kernel; (void)kernel_cap;
+    return fail(c, DEMON_ERR_INVALID, "libdemon_hip.so was built without -DDEMON_TIMELINE (see tools/timeline.py)");
+#else
+    int r = check_batch(c, n);
+    if (r) return r;
+    if (!layer_name || !records || !count || cap < 1) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    hipSetDevice(c->device);
+    Layer *L = nullptr;
+    for (auto &l : c->layers) if (l->name == layer_name) L = l.get();
+    if (!L) return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown layer ") + layer_name);
+    const size_t max_wg = 1u << 16;
+    unsigned long long *buf = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&buf, max_wg * 64));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float *ws = c->d_ws;
+    for (int i = 0; i < 3; ++i) run_layer(L, n, c->stream, ws);   // warm
+    hipMemsetAsync(buf, 0, max_wg * 64, c->stream);
+    hipStreamSynchronize(c->stream);
+    g_timeline_dev = buf;
+    hipEventRecord(e0, c->stream);
+    run_layer(L, n, c->stream, ws);
+    hipEventRecord(e1, c->stream);
+    g_timeline_dev = nullptr;
+    hipError_t err = hipStreamSynchronize(c->stream);
+    if (kernel && kernel_cap > 0 && g_last_kernel) { strncpy(kernel, g_last_kernel, kernel_cap - 1); kernel[kernel_cap - 1] = 0; }
+    float t = 0;
+    hipEventElapsedTime(&t, e0, e1);
+    if (ms) *ms = t;
+    std::vector<unsigned long long> host(max_wg * 8);
+    if (err == hipSuccess) err = hipMemcpy(host.data(), buf, max_wg * 64, hipMemcpyDeviceToHost);
+    hipFree(buf);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(c, DEMON_ERR_HIP, "timeline run failed");
+    int k = 0;
+    for (size_t w = 0; w < max_wg && k < cap; ++w)
+        if (host[8 * w]) { memcpy(records + 8 * (size_t)k, &host[8 * w], 64); ++k; }
+    *count = k;
+    return DEMON_OK;
+#endif
 }
 
 int demon_op_conv2d(demon_ctx *c, float *out, const float *in, const float *w_hwio, const float *bias, int n, int cin, int h,

@@ -43,6 +43,42 @@ __device__ __forceinline__ void xcd_tile(int mode, unsigned bx_in, unsigned by_i
     by = q - bx * gy;
 }
 
+// Diagnostic build only (-DDEMON_TIMELINE, tools/timeline.py): every workgroup of a contraction kernel records wall-clock
+// stamps (s_memrealtime, 100 MHz) at kernel entry, after its prologue, after its K loop and after its stores have drained,
+// plus the XCC / CU it ran on: record = 8 x u64 at index (linear workgroup id).  The product build compiles TlScope to nothing.
+#ifdef DEMON_TIMELINE
+struct TlScope {
+    unsigned long long *rec;
+    __device__ __forceinline__ TlScope(unsigned long long *base)
+    {
+        rec = nullptr;
+        if (base && threadIdx.x == 0) {
+            const unsigned long wg = blockIdx.x + (unsigned long)gridDim.x * (blockIdx.y + (unsigned long)gridDim.y * blockIdx.z);
+            rec = base + 8 * wg;
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            rec[4] = hw;
+            rec[5] = xcc;
+            rec[0] = wall_clock64();
+        }
+    }
+    __device__ __forceinline__ void mark(int slot) { if (rec) rec[slot] = wall_clock64(); }
+    __device__ __forceinline__ ~TlScope()
+    {
+        if (rec) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            rec[3] = wall_clock64();
+        }
+    }
+};
+#else
+struct TlScope {
+    __device__ __forceinline__ TlScope(unsigned long long *) {}
+    __device__ __forceinline__ void mark(int) {}
+};
+#endif
+
 struct KEntry {
     int delta;  // ci*H*W + dy*W + dx   (elements)
     int dydx;   // (dy << 16) | (dx & 0xffff);  dy = -30000 marks padding rows (k >= K)
@@ -74,6 +110,7 @@ struct ConvArgs {
     int ksplit;         // number of K slices (1 = fused epilogue)
     int xcd;            // 1: XCD-aware tile order (xcd_tile)
     long out_plane;     // elements between output channel planes (Ho*Wo unless the buffer is padded)
+    unsigned long long *tl;  // timeline records (diagnostic build), else null
 };
 
 enum ConvTile { TILE_128x128 = 0, TILE_64x128, TILE_32x128, TILE_64x64, TILE_32x64, TILE_32x32, TILE_128x32, TILE_64x32, TILE_COUNT };
@@ -85,6 +122,23 @@ int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);
 
 void launch_splitk_reduce(const ConvArgs &a, int nclasses, hipStream_t stream);
+
+// ---- register-streaming contraction for the deep small-map layers (conv_stream.hip) -----------------------------------------
+struct StreamArgs {
+    ConvArgs c;            // geometry, pointers, epilogue and split-K fields as for the im2col kernel (c.wp / c.ktab unused)
+    const float *wf;       // weights in MFMA fragment order [cls][step][Mpad/32][64][8] (stream_repack_kernel)
+    const float *zero;     // >= (Cin + 1) * H * W zeros: what taps outside the image read
+    long cls_wf_stride;    // floats between classes = K * Mpad
+    int ntaps, csteps, nsteps;  // taps per class, Cin / 16, ntaps * csteps
+    int tapdy[4][9], tapdx[4][9];  // per class and tap: input offset relative to the anchor pixel
+    int dbg;               // diagnostic builds (-DDEMON_STREAM_DBG): bit 0 skip the A loads, bit 1 skip the B loads
+};
+constexpr int STREAM_VARIANTS = 10;  // (waves along Cout, row blocks per wave, column blocks per wave), see conv_stream.hip
+int stream_variant_waves(int v);
+int stream_variant_bm(int v);
+int stream_variant_bn(int v);
+void launch_stream_repack(float *wf, const float *wp, int ncls, int K, int Mpad, long cls_w_stride, hipStream_t s);
+void launch_conv_stream(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
 
 // ---- patch-staged convolution (conv_patch.hip) ---------------------------------------------------------
 constexpr int PATCH_EPT = 8;  // patch elements a thread stages per K-step
@@ -113,6 +167,7 @@ struct PatchArgs {
     int xcd;             // 1: XCD-aware tile order (xcd_tile)
     // magic numbers for exact unsigned division of the small prologue indices: n / d == mulhi(n, ceil(2^32 / d)) for n < 2^20, d < 2^12
     unsigned m_plane, m_pw, m_thtw, m_tw, m_tilesx, m_tilesy;
+    unsigned long long *tl;  // timeline records (diagnostic build), else null
 };
 enum PatchTileId { PTILE_128x128 = 0, PTILE_64x128, PTILE_32x128, PTILE_64x64, PTILE_128x64, PTILE_32x64, PTILE_16x128, PTILE_DC4_32x128, PTILE_DC4_64x64, PTILE_COUNT };
 bool patch_tile_is_dc4(int tile);  // fused 4-class transposed-conv kernel (deconv4_kernel)

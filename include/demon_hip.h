@@ -93,7 +93,8 @@ int demon_set_option(demon_ctx *ctx, const char *key, int value);
 /* Times every applicable kernel variant (im2col / patch-staged, tile shape, split-K) of every layer at batch n on
  * this GPU and keeps the fastest per layer (~1 s; results do not change, only launch plans). */
 int demon_autotune(demon_ctx *ctx, int n);
-/* read back / install launch plans (kind 0 = im2col kernel, 1 = patch-staged kernel; tile id; split-K), e.g. to ship
+/* read back / install launch plans (kind 0 = im2col kernel, 1 = patch-staged kernel, 3 = small-Cout VALU kernel, 4 = register-
+ * streaming kernel; tile id; split-K), e.g. to ship
  * the result of one autotune run as a file.  demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
 int demon_num_layers(const demon_ctx *ctx);
 int demon_plan_get(const demon_ctx *ctx, int n, int layer_index, char *name, int name_cap, int *kind, int *tile, int *ksplit);
@@ -145,6 +146,12 @@ typedef struct demon_launch_record {
 } demon_launch_record;
 int demon_profile_full(demon_ctx *ctx, int n, int iterations, int repeats, demon_launch_record *records, int cap,
                        int *count);
+
+/* Diagnostic builds only (hipcc -DDEMON_TIMELINE, tools/timeline.py): per-workgroup wall-clock records (8 x uint64 each: entry,
+ * prologue done, K loop done, stores drained [100 MHz ticks], HW_ID, XCC_ID, 0, 0) of one launch of the named layer at batch n;
+ * the product build returns DEMON_ERR_INVALID. */
+int demon_debug_timeline(demon_ctx *ctx, const char *layer_name, int n, uint64_t *records, int cap, int *count, float *ms,
+                         char *kernel, int kernel_cap);
 
 /* ---- lmbspecialops-level entry points (host buffers) -------------------------------------------------
  * Replace the lmbspecialops custom ops the reference calls:
@@ -207,7 +214,8 @@ int demon_op_dense(demon_ctx *ctx, float *out, const float *in, const float *w_i
 
 /* ---- tuning / diagnostics ----------------------------------------------------------------------------
  * Times one contraction layer (kind 0 conv, 1 transposed conv k4 s2, 2 dense) on device-resident random
- * data with hip events; tile < 0 / ksplit <= 0 select the automatic plan.  Not on the reference's path. */
+ * data with hip events; tile < 0 / ksplit <= 0 select the automatic plan (tile 0..7 im2col tiles, 100 + t patch tiles,
+ * 200 + v streaming-kernel variants).  Not on the reference's path. */
 int demon_bench_layer(demon_ctx *ctx, int kind, int n, int cin, int h, int w, int cout, int kh, int kw, int sh,
                       int sw, int tile, int ksplit, int iters, float *avg_ms, double *flops);
 

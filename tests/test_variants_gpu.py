@@ -21,6 +21,7 @@ LAYERS = [
     ("conv", 64, 16, 3, 3, 1, 1, 48, 64), ("conv", 64, 16, 3, 3, 1, 1, 21, 37), ("conv", 30, 12, 3, 3, 2, 2, 24, 32),
     ("deconv", 512, 256, 0, 0, 0, 0, 6, 8), ("deconv", 514, 128, 0, 0, 0, 0, 12, 16), ("deconv", 128, 32, 0, 0, 0, 0, 24, 32),
     ("deconv", 128, 64, 0, 0, 0, 0, 17, 35), ("deconv", 4, 2, 0, 0, 0, 0, 6, 8), ("deconv", 30, 40, 0, 0, 0, 0, 9, 50),
+    ("conv", 16, 40, 3, 3, 1, 1, 7, 9), ("conv", 48, 32, 1, 5, 1, 2, 5, 23), ("deconv", 16, 8, 0, 0, 0, 0, 3, 5),
 ]
 
 
@@ -49,11 +50,37 @@ def test_all_variants_agree(gpu_ctx, layer):
     b = rng.standard_normal((cout,)).astype(np.float32)
     want = _ref(kind, x, w, b, (sh, sw))
     plans = [(3, 0, 0)] + [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(9) for ks in (0, 2, 3, 5)]
+    plans += [(4, v, ks) for v in range(10) for ks in (1, 2, 3, 5)]   # register-streaming kernel (applies when Cin % 16 == 0)
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
             got = gpu_ctx.deconv4x4s2(x, w, b, lrelu=True) if kind == "deconv" else gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
             err = rel_l1(got, want)
             assert err < 1e-5, "plan %s: rel L1 %.3e" % (plan, err)
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+def test_streaming_kernel_is_bit_identical_to_im2col_and_runs_dense(gpu_ctx):
+    """conv_stream.hip reduces in the same order as conv_mfma.hip (tap major, channel minor), so without split-K the two give
+    the same bits; the dense layers (H = W = 1, one tap) run on it too"""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((5, 256, 12, 16)).astype(np.float32)
+    w = (rng.standard_normal((3, 1, 256, 256)) / 28).astype(np.float32)
+    b = rng.standard_normal(256).astype(np.float32)
+    try:
+        os.environ["DEMON_FORCE_PLAN"] = "0,6,1"
+        ref = gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True)
+        for v in range(10):
+            os.environ["DEMON_FORCE_PLAN"] = "4,%d,1" % v
+            np.testing.assert_array_equal(gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True), ref)
+        xd = rng.standard_normal((7, 6144)).astype(np.float32)
+        wd = (rng.standard_normal((6144, 1024)) / 78).astype(np.float32)
+        bd = rng.standard_normal(1024).astype(np.float32)
+        want = xd.astype(np.float64) @ wd.astype(np.float64) + bd
+        want = np.where(want >= 0, want, 0.1 * want)
+        for plan in ("4,0,1", "4,0,8", "4,4,48", "4,2,16"):
+            os.environ["DEMON_FORCE_PLAN"] = plan
+            assert rel_l1(gpu_ctx.dense(xd, wd, bd, lrelu=True), want) < 1e-5, plan
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
