@@ -65,7 +65,9 @@ def build(force=False, verbose=False, extra_flags=(), tag=""):
 
 
 if __name__ == "__main__":
-    if "--dbg" in sys.argv:
+    if "--pipe-mid" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_PIPE_MID"], tag="mid"))
+    elif "--dbg" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_STREAM_DBG"], tag="dbg"))
     elif "--timeline" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_TIMELINE"], tag="tl"))

@@ -86,12 +86,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
             oklast |= ((ok && last_c0 + c < a.Cin) ? 1u : 0u) << i;
         }
     }
+    const int dummy_off = 2 * KD * BM + 2 * patch_floats + 4 * tid;  // floats from smem: this thread's 16-byte dummy slot
+#pragma unroll
+    for (int i = 1; i < EPT; ++i)
+        if (!((wrbits >> i) & 1u)) goff[i] = goff[0];
     // ---- A loader: chunk q = tid + i*NT of the [KD][BM/4] tile; row r = tap*CKS + cl  <->  packed row tap*Cin + c0 + cl
     int aoff[APER];
 #pragma unroll
     for (int i = 0; i < APER; ++i) {
         const int q = tid + i * NT;
-        const int r = q / (BM / 4), c4 = q - r * (BM / 4);
+        const int qc = q < A4 ? q : A4 - 1;
+        const int r = qc / (BM / 4), c4 = qc - r * (BM / 4);
         aoff[i] = ((r / CKS) * a.Cin + (r % CKS)) * a.Mpad + m0 + c4 * 4;
     }
 
@@ -127,57 +132,88 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     // (~2300+ cycles) to return before anybody waits for it
     float pregA[EPT], pregB[EPT];
     floatx4 aregA[APER], aregB[APER];
-    auto load_patch_one = [&](float (&preg)[EPT], int i, const float *__restrict__ base) {
-        // only real elements: a dummy load of one shared address from every wave of every workgroup is an L2 hot spot
-        if ((wrbits >> i) & 1u) preg[i] = base[goff[i]];
-    };
+    // Branch-free staging: slots past the end of the patch / A tile (the last i of a thread) load this thread's own element 0
+    // again (a valid, thread-private address: one shared dummy address for every wave would be an L2 hot spot) and store it
+    // to a private dummy slot behind the tiles, so the K loop carries no exec-mask branches.
+    auto load_patch_one = [&](float (&preg)[EPT], int i, const float *__restrict__ base) { preg[i] = base[goff[i]]; };
     auto load_a_one = [&](floatx4 (&areg)[APER], int i, const float *__restrict__ base) {
-        if (A4 % NT == 0 || tid + i * NT < A4) areg[i] = *reinterpret_cast<const floatx4 *>(base + aoff[i]);
+        areg[i] = *reinterpret_cast<const floatx4 *>(base + aoff[i]);
+    };
+    auto store_patch_one = [&](const float (&preg)[EPT], int i, int buf, unsigned ok) {
+        smem[((wrbits >> i) & 1u) ? 2 * KD * BM + buf * patch_floats + loff[i] : dummy_off] = ((ok >> i) & 1u) ? preg[i] : 0.0f;
+    };
+    auto store_a_one = [&](const floatx4 (&areg)[APER], int i, int buf) {
+        *reinterpret_cast<floatx4 *>(smem + ((A4 % NT == 0 || tid + i * NT < A4) ? buf * (KD * BM) + (tid + i * NT) * 4 : dummy_off)) = areg[i];
     };
     auto store_tiles = [&](const float (&preg)[EPT], const floatx4 (&areg)[APER], int buf, unsigned ok) {
-        float *P = Ps + buf * patch_floats;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i)
-            if ((wrbits >> i) & 1u) P[loff[i]] = ((ok >> i) & 1u) ? preg[i] : 0.0f;
-        float *A = As + buf * (KD * BM);
+        for (int i = 0; i < EPT; ++i) store_patch_one(preg, i, buf, ok);
 #pragma unroll
-        for (int i = 0; i < APER; ++i)
-            if (A4 % NT == 0 || tid + i * NT < A4) *reinterpret_cast<floatx4 *>(A + (tid + i * NT) * 4) = areg[i];
+        for (int i = 0; i < APER; ++i) store_a_one(areg, i, buf);
     };
 
-    auto kstep = [&](int buf, int next, float (&preg)[EPT], floatx4 (&areg)[APER], auto prefetch) {
-        constexpr bool PREFETCH = decltype(prefetch)::value;
+    // Fragments of one K-step live in av / bv; the groups [0, G1) ("first half") of step s+1 are read from LDS while the second
+    // half of step s is in the matrix pipe, the groups [G1, NG) of step s while its first half is -- so no MFMA ever waits for
+    // an LDS read issued just before it, and the one barrier of the step sits BETWEEN the two halves:
+    //   first half  : MFMAs [0,G1) | ds_read of groups [G1,NG) of this step | global loads of step s+2 | ds_write of step s+1
+    //   barrier     : step s+1 is complete in the other LDS buffer (everybody finished reading it a step ago, see below)
+    //   second half : MFMAs [G1,NG) | ds_read of groups [0,G1) of step s+1
+    // Buffer safety: the buffer written during the first half of step s held step s-1; its last reads (second-half groups of
+    // step s-1) were issued before the barrier of step s-1, which every wave has passed by now.
+    constexpr int G1 = NG / 2 > 0 ? NG / 2 : 1, G2 = NG - G1;
+    float av[NG][TM], bv[NG][TN];
+    auto read_group = [&](int buf, int kk) {
         const char *Pb = reinterpret_cast<const char *>(Ps + buf * patch_floats);
         const float *A = As + buf * (KD * BM);
-        float av[NG][TM], bv[NG][TN];
+        const int k = KG * kk + lhi;
 #pragma unroll
-        for (int kk = 0; kk < NG; ++kk) {
-            const int k = KG * kk + lhi;
+        for (int i = 0; i < TM; ++i) av[kk][i] = A[k * BM + (wm * TM + i) * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[kk][i] = A[k * BM + (wm * TM + i) * 32 + l31];
+        for (int j = 0; j < TN; ++j) bv[kk][j] = *reinterpret_cast<const float *>(Pb + bbase[j] + so[kk]);
+    };
+    auto mfma_group = [&](int g) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[kk][j] = *reinterpret_cast<const float *>(Pb + bbase[j] + so[kk]);
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
+            }
+    };
+    // LOADS: global loads of step `next` into (lpreg, lareg); STORE: (spreg, sareg) hold step s+1 and go to the other buffer
+    auto kstep = [&](int buf, int next, float (&lpreg)[EPT], floatx4 (&lareg)[APER], const float (&spreg)[EPT],
+                     const floatx4 (&sareg)[APER], unsigned sok, auto loads, auto store) {
+        constexpr bool LOADS = decltype(loads)::value, STORE = decltype(store)::value;
         const float *__restrict__ pbase = in0 + (long)next * CKS * a.H * a.W;
         const float *__restrict__ abase = wp + (long)next * CKS * a.Mpad;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
+        for (int g = 0; g < G1; ++g) {
+            mfma_group(g);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int kk = G1 + g * G2 / G1; kk < G1 + (g + 1) * G2 / G1; ++kk) read_group(buf, kk);
+            if (LOADS) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (M16) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i], bv[g][j], acc[i][j], 0, 0, 0);
-                }
-            if (PREFETCH) {
-                constexpr int GH = NG / 2 > 0 ? NG / 2 : 1;  // loads behind the first half of the groups
-                if (g < GH) {
+                for (int i = g * EPT / G1; i < (g + 1) * EPT / G1; ++i) load_patch_one(lpreg, i, pbase);
 #pragma unroll
-                    for (int i = g * EPT / GH; i < (g + 1) * EPT / GH; ++i) load_patch_one(preg, i, pbase);
+                for (int i = g * APER / G1; i < (g + 1) * APER / G1; ++i) load_a_one(lareg, i, abase);
+            }
+            if (STORE) {
 #pragma unroll
-                    for (int i = g * APER / GH; i < (g + 1) * APER / GH; ++i) load_a_one(areg, i, abase);
-                }
+                for (int i = g * EPT / G1; i < (g + 1) * EPT / G1; ++i) store_patch_one(spreg, i, buf ^ 1, sok);
+#pragma unroll
+                for (int i = g * APER / G1; i < (g + 1) * APER / G1; ++i) store_a_one(sareg, i, buf ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (STORE) __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = G1; g < NG; ++g) {
+            mfma_group(g);
+            if (STORE) {
+#pragma unroll
+                for (int kk = (g - G1) * G1 / G2; kk < (g - G1 + 1) * G1 / G2; ++kk) read_group(buf ^ 1, kk);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -189,7 +225,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     auto okmask_of = [&](int step) { return step == a.nsteps_total - 1 ? oklast : okbits; };
     auto phys = [&](int x) { return s_begin + min(x, nsteps - 1); };  // step of this K slice; a run-ahead past the end re-reads the last one
     if (nsteps > 0) {
-        // prologue: step 0 -> LDS buffer 0; step 1 -> register set B (stored at the end of step 0)
+        // prologue: step 0 -> LDS buffer 0; step 1 -> register set B (goes to LDS during step 0)
         const int p0s = phys(0);
         const float *__restrict__ pbase = in0 + (long)p0s * CKS * a.H * a.W;
         const float *__restrict__ abase = wp + (long)p0s * CKS * a.Mpad;
@@ -210,24 +246,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     }
     __syncthreads();
     tl.mark(1);
-    // during step s (buffer s&1): MFMAs on step s, loads of step s+2 into the set that step s freed, then the
-    // set holding step s+1 goes to LDS buffer (s+1)&1.  Pairs of steps keep the set indices static.
+    if (nsteps > 0) {
+#pragma unroll
+        for (int kk = 0; kk < G1; ++kk) read_group(0, kk);
+    }
+    // during step s (buffer s&1): MFMAs on step s, loads of step s+2 into the set that step s freed, the set holding step s+1
+    // goes to LDS buffer (s+1)&1.  Pairs of steps keep the set indices static.
     int s = 0;
     for (; s + 2 < nsteps; s += 2) {
-        kstep(0, phys(s + 2), pregA, aregA, std::true_type{});
-        store_tiles(pregB, aregB, 1, okmask_of(phys(s + 1)));
-        __syncthreads();
-        kstep(1, phys(s + 3), pregB, aregB, std::true_type{});
-        store_tiles(pregA, aregA, 0, okmask_of(phys(s + 2)));
-        __syncthreads();
+        kstep(0, phys(s + 2), pregA, aregA, pregB, aregB, okmask_of(phys(s + 1)), std::true_type{}, std::true_type{});
+        kstep(1, phys(s + 3), pregB, aregB, pregA, aregA, okmask_of(phys(s + 2)), std::true_type{}, std::true_type{});
     }
     if (s + 1 < nsteps) {
-        kstep(0, 0, pregA, aregA, std::false_type{});
-        store_tiles(pregB, aregB, 1, okmask_of(phys(s + 1)));
-        __syncthreads();
-        ++s;
+        kstep(0, 0, pregA, aregA, pregB, aregB, okmask_of(phys(s + 1)), std::false_type{}, std::true_type{});
+        kstep(1, 0, pregA, aregA, pregA, aregA, 0u, std::false_type{}, std::false_type{});
+    } else if (nsteps > 0) {
+        kstep(0, 0, pregA, aregA, pregA, aregA, 0u, std::false_type{}, std::false_type{});
     }
-    if (nsteps > 0) kstep(s & 1, 0, pregA, aregA, std::false_type{});
     tl.mark(2);
 
     // ---- epilogue
@@ -575,7 +610,8 @@ size_t patch_lds_bytes(int tile, int ntaps, int G, int PS)
 {
     const int cks = patch_cks(ntaps, tile);
     const size_t a_tiles = patch_tile_is_dc4(tile) ? 4 : 1;  // the fused transposed conv stages the weights of its four classes
-    return sizeof(float) * (2ul * a_tiles * ntaps * cks * kPatchTiles[tile].bm + 2ul * G * cks * PS);
+    // + one 16-byte dummy slot per thread (conv_patch_kernel's branch-free staging; the fused transposed conv does not use it)
+    return sizeof(float) * (2ul * a_tiles * ntaps * cks * kPatchTiles[tile].bm + 2ul * G * cks * PS + 4ul * kPatchTiles[tile].threads);
 }
 
 template <int BM, int WM, int WN, int TM, int TN, int EPT>

@@ -3,8 +3,9 @@
 writes it to <outdir>/plan_<H>x<W>_n<N>.json (copy into demon_amd/tuned/ to ship it).
 usage: python tools/tune.py --height 192 --width 256 --batch 32 [--rounds 3] [--outdir gpurun_out]"""
 import argparse, collections, json, os, sys
+import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from demon_amd import DemonContext  # noqa: E402
+from demon_amd import DemonContext, weights as W  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--height", type=int, default=192)
@@ -17,6 +18,14 @@ args = ap.parse_args()
 os.makedirs(args.outdir, exist_ok=True)
 for n in args.batch:
     ctx = DemonContext(0, n, args.height, args.width, version=args.version)
+    # real weights and activations in every buffer: all-zero operands clock higher and would bias the comparison
+    ctx.set_weights(W.synthetic_weights(seed=1, height=args.height, width=args.width, version=args.version))
+    rng = np.random.default_rng(0)
+    pair = rng.random((n, 6, args.height, args.width), dtype=np.float32) - np.float32(0.5)
+    img2_2 = pair[:, 3:6].reshape(n, 3, args.height // 4, 4, args.width // 4, 4).mean(axis=(3, 5)).astype(np.float32)
+    ctx.upload_inputs(pair, img2_2)
+    ctx.run_full(n, 3)
+    ctx.synchronize()
     votes = collections.defaultdict(collections.Counter)
     for _ in range(args.rounds):
         ctx.autotune(n)
