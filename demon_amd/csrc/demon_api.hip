@@ -83,6 +83,9 @@ struct Step {
     // stream.  side = 1 marks them; fork = 1 on the first one (side stream waits for everything enqueued so far on the main
     // stream); join = 1 on the first MAIN step that needs their results (main stream waits for the side stream).
     int side = 0, fork = 0, join = 0;
+    // extra-input assembly exists twice: fused = 1 is the single fused launch (option fused_inputs, default), fused = 2 marks the
+    // chain of stand-alone op launches it replaces (depth_to_flow / warp2d / copy_channels / flow_to_depth / upsample)
+    int fused = 0;
 };
 
 struct Variable {
@@ -118,6 +121,7 @@ struct demon_ctx {
     std::vector<hipEvent_t> events;  // fork / join events, one per use inside a sequence
     int opt_side_branches = 1;
     int opt_fused_pairs = 1;  // conv_pair.hip for the pairs conv_pair_applies() selects
+    int opt_fused_inputs = 1;  // one launch for the extra-input assembly of the iterative blocks / the refinement input
     // all packed kernels and biases of the networks live in ONE device slab (alloc_weight_slab), so that
     // demon_broadcast_weights is a single RCCL broadcast of device-resident, already packed data
     float *w_slab = nullptr;
@@ -773,9 +777,11 @@ struct Builder {
     // even input sizes of this net puts (k - stride) // 2 zeros in front and the rest behind
     bool same = false;
     int side = 0, fork_next = 0, join_next = 0;  // see Step::side
+    int fused = 0;  // Step::fused of the steps created while it is set
+    int fork_hold = 0;  // the fused step and the first step of the chain it replaces both carry the fork
     void stamp(Step &st)
     {
-        st.side = side; st.fork = fork_next; st.join = join_next;
+        st.side = side; st.fork = fork_next; st.join = join_next; st.fused = fused;
         fork_next = 0; join_next = 0;
     }
 
@@ -962,6 +968,16 @@ void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope
         View img2 = c->image2_2, depth2 = c->depth2, normal2 = c->normal2;
         float *rot = c->d_rot, *trans = c->d_trans, *intr = c->d_intrinsics;
         const double px = (double)h2 * w2 * 4;
+        {
+            View dn = depth2;  // depth2 / normal2 are the slices [0,1) / [1,4) of one 4-channel buffer
+            b.fused = 1;
+            b.op("assemble_inputs", "assemble_flow_inputs", px * (4 + 3 + 9), [=](int n, hipStream_t s) {
+                launch_assemble_flow_inputs(extra.ptr(), extra.n_stride(), img2.ptr(), img2.n_stride(), dn.ptr(), dn.n_stride(), intr, rot, trans,
+                                            n, h2, w2, s);
+            });
+            b.fused = 2;
+            b.fork_next = 1;
+        }
         b.op("depth_to_flow", "depth_to_flow", px * 3, [=](int n, hipStream_t s) {
             launch_depth_to_flow(extra.slice(3, 2).ptr(), depth2.ptr(), depth2.n_stride(), intr, rot, trans, n, h2, w2,
                                  extra.n_stride(), 1, 1, 1, s);
@@ -976,6 +992,7 @@ void build_flow(demon_ctx *c, std::vector<Step> *steps, const std::string &scope
             launch_copy_channels(extra.slice(6, 3).ptr(), extra.n_stride(), normal2.ptr(), normal2.n_stride(), n, 3,
                                  (long)h2 * w2, s);
         });
+        b.fused = 0;
         b.conv2("conv2_extra_inputs", extra, conv2cat.slice(32, 32), 3, 1);
         b.side = 0;
         b.steps = steps;
@@ -1040,6 +1057,18 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
     View extra = buffer(c, iterative ? "extra_dm8" : "extra_dm7", nextra, h2, w2);
     View img2 = c->image2_2, flowconf2 = c->flowconf2;
     const double px = (double)h2 * w2 * 4;
+    {
+        float *rot = c->d_rot, *trans = c->d_trans, *intr = c->d_intrinsics;
+        demon_ctx *cc = c;
+        const int with_depth = iterative ? 1 : 0;
+        b.fused = 1;
+        b.op("assemble_inputs", "assemble_dm_inputs", px * (4 + 3 + nextra), [=](int n, hipStream_t s) {
+            launch_assemble_dm_inputs(extra.ptr(), extra.n_stride(), img2.ptr(), img2.n_stride(), flowconf2.ptr(), flowconf2.n_stride(), intr, rot,
+                                      trans, n, h2, w2, with_depth, v2 ? 1 : cc->opt_f2d_method, v2 ? 50.0f : 0.0f, s);
+        });
+        b.fused = 2;
+        b.fork_next = 1;
+    }
     b.op("warp2d", "warp2d", px * 8, [=](int n, hipStream_t s) {
         launch_warp2d(extra.ptr(), extra.n_stride(), img2.ptr(), img2.n_stride(), flowconf2.ptr(), flowconf2.n_stride(), n,
                       3, h2, w2, 1, 1, 0.0f, s);
@@ -1057,6 +1086,7 @@ void build_dm(demon_ctx *c, std::vector<Step> *steps, const std::string &scope, 
                                  rot, trans, n, h2, w2, 1, 1, v2 ? 1 : cc->opt_f2d_method, v2 ? 50.0f : 0.0f, s);
         });
     }
+    b.fused = 0;
     b.conv2("conv2_extra_inputs", extra, conv2cat.slice(32, 32), 3, 1);
     b.side = 0;
     b.steps = steps;
@@ -1125,10 +1155,16 @@ void build_refine(demon_ctx *c, std::vector<Step> *steps)
     View r1 = buffer(c, "refine_conv1", 64, h1, w1), r2 = buffer(c, "refine_conv2", 128, h2, w2),
          r2_1 = buffer(c, "refine_conv2_1", 128, h2, w2);
     View image_pair = c->image_pair, depth2 = c->depth2;
+    b.fused = 1;
+    b.op("assemble_input", "assemble_refine_input", 4.0 * (4.0 * H * W + 3.0 * H * W + h2 * w2), [=](int n, hipStream_t s) {
+        launch_assemble_refine_input(inp.ptr(), inp.n_stride(), image_pair.ptr(), image_pair.n_stride(), depth2.ptr(), depth2.n_stride(), n, H, W, 4, s);
+    });
+    b.fused = 2;
     b.op("assemble_input", "upsample_nearest", 4.0 * (4.0 * H * W + 3.0 * H * W + h2 * w2), [=](int n, hipStream_t s) {
         launch_copy_channels(inp.ptr(), inp.n_stride(), image_pair.ptr(), image_pair.n_stride(), n, 3, (long)H * W, s);
         launch_upsample_nearest(inp.slice(3, 1).ptr(), inp.n_stride(), depth2.ptr(), depth2.n_stride(), n, 1, h2, w2, 4, s);
     });
+    b.fused = 0;
     b.conv("conv0", inp, concat0.slice(32, 32), 3, 1, 1);
     b.conv("conv1", concat0.slice(32, 32), r1, 3, 2, 1);
     b.conv("conv1_1", r1, concat1.slice(64, 64), 3, 1, 1);
@@ -1166,6 +1202,7 @@ void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t 
         if (st.image_only == 2 && mode != 2) continue;
         if (st.image_only == 3 && mode != 1) continue;
         if ((st.pair == 1 && !c->opt_fused_pairs) || (st.pair == 2 && c->opt_fused_pairs)) continue;
+        if ((st.fused == 1 && !c->opt_fused_inputs) || (st.fused == 2 && c->opt_fused_inputs)) continue;
         if (!branches) { st.fn(n, s); continue; }
         if (st.fork && ev < c->events.size()) {
             hipEventRecord(c->events[ev], s);
@@ -1209,8 +1246,8 @@ int run_sequence(demon_ctx *c, int kind, int n, int iterations)
         return DEMON_OK;
     }
     char key[64];
-    snprintf(key, sizeof key, "%d:%d:%d:%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method, c->opt_reuse_image, c->opt_side_branches,
-             c->opt_fused_pairs);
+    snprintf(key, sizeof key, "%d:%d:%d:%d:%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method, c->opt_reuse_image, c->opt_side_branches,
+             c->opt_fused_pairs, c->opt_fused_inputs);
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
         hipGraph_t graph = nullptr;
@@ -1595,6 +1632,7 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
     }
     if (!strcmp(key, "reuse_image_features")) { c->opt_reuse_image = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "fused_pairs")) { c->opt_fused_pairs = value ? 1 : 0; return DEMON_OK; }
+    if (!strcmp(key, "fused_inputs")) { c->opt_fused_inputs = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "side_branches")) { c->opt_side_branches = (value && c->side_stream && c->d_ws_side != c->d_ws) ? 1 : 0; return DEMON_OK; }
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }
@@ -1811,7 +1849,8 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
     // the two layer steps, never both; the image-feature cache steps only exist with reuse_image_features
     std::vector<const Step *> seq;
     auto active = [c](const Step &s) {
-        return s.image_only < 2 && !((s.pair == 1 && !c->opt_fused_pairs) || (s.pair == 2 && c->opt_fused_pairs));
+        return s.image_only < 2 && !((s.pair == 1 && !c->opt_fused_pairs) || (s.pair == 2 && c->opt_fused_pairs)) &&
+               !((s.fused == 1 && !c->opt_fused_inputs) || (s.fused == 2 && c->opt_fused_inputs));
     };
     for (auto &s : c->net_boot) if (active(s)) seq.push_back(&s);
     for (int i = 0; i < iterations; ++i)

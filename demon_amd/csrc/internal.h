@@ -226,6 +226,15 @@ void launch_flow_to_depth(float *out, long out_n_stride, const float *flow, long
 void launch_warp2d(float *out, long out_n_stride, const float *in, long in_n_stride, const float *disp,
                    long disp_n_stride, int N, int C, int H, int W, int normalized, int border_mode,
                    float border_value, hipStream_t s);
+// fused extra-input assembly of the iterative blocks and of the refinement net (one launch each; bit-identical to the op chains)
+void launch_assemble_flow_inputs(float *extra, long extra_n_stride, const float *img2, long img2_n_stride, const float *dn,
+                                 long dn_n_stride, const float *intrinsics, const float *rotation, const float *translation, int N, int H,
+                                 int W, hipStream_t s);
+void launch_assemble_dm_inputs(float *extra, long extra_n_stride, const float *img2, long img2_n_stride, const float *flowconf,
+                               long fc_n_stride, const float *intrinsics, const float *rotation, const float *translation, int N, int H,
+                               int W, int with_depth, int method, float clip_hi, hipStream_t s);
+void launch_assemble_refine_input(float *out, long out_n_stride, const float *image, long image_n_stride, const float *depth2,
+                                  long depth_n_stride, int N, int H, int W, int factor, hipStream_t s);
 void launch_leaky_relu(float *out, const float *in, long count, float leak, hipStream_t s);
 void launch_replace_nonfinite(float *out, const float *in, long count, float value, hipStream_t s);
 void launch_sig(float *out, const float *in, int NC, int H, int W, const int *deltas, const float *weights,

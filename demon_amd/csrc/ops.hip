@@ -2,7 +2,9 @@
 //
 // Every kernel maps one 64-lane wavefront onto 64 consecutive pixels of an image row segment so that
 // all streaming loads/stores are 256-byte coalesced; per-sample camera parameters are wave-uniform.
-// Arithmetic is written in the same operation order as the CPU oracle so the two agree to rounding.
+// Arithmetic is written in the same operation order as the CPU oracle so the two agree to rounding; the per-pixel geometry
+// functions are compiled without FMA contraction, so that the fused assembly kernels (which inline several of them) give the
+// same bits as the chains of stand-alone op launches they replace.
 //
 //   depth_to_flow (+ |flow|<1 gate)  blocks_original.py:155-168
 //   flow_to_depth / flow_to_depth2   blocks_original.py:344-360, v2/blocks.py:362-378
@@ -21,6 +23,7 @@ namespace demon {
 // angle-axis -> rotation matrix, helpers.py:37-57 (identity when angle <= 1e-6)
 __device__ __forceinline__ void angleaxis_to_rotation(const float *__restrict__ aa, float R[9])
 {
+#pragma clang fp contract(off)  // same roundings wherever this is inlined (and as the oracle's plain C): see the header comment
     const float ax = aa[0], ay = aa[1], az = aa[2];
     const float angle = sqrtf(ax * ax + ay * ay + az * az);
     if (angle > 1e-6f) {
@@ -32,6 +35,50 @@ __device__ __forceinline__ void angleaxis_to_rotation(const float *__restrict__ 
         R[6] = uz * ux * omc - uy * s; R[7] = uz * uy * omc + ux * s; R[8] = c + uz * uz * omc;
     } else {
         R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    }
+}
+
+// per-sample camera of the geometry ops: intrinsics in pixels, rotation matrix, translation
+struct Camera {
+    float fx, fy, cx, cy, ifx, ify;
+    float R[9];
+    float t[3];
+};
+__device__ __forceinline__ Camera load_camera(const float *__restrict__ intrinsics, const float *__restrict__ rotation,
+                                              const float *__restrict__ translation, int n, int H, int W)
+{
+#pragma clang fp contract(off)  // same roundings wherever this is inlined (and as the oracle's plain C): see the header comment
+    Camera c;
+    const float *K = intrinsics + 4 * n;
+    c.fx = K[0] * W; c.fy = K[1] * H; c.cx = K[2] * W; c.cy = K[3] * H;
+    c.ifx = 1.0f / c.fx; c.ify = 1.0f / c.fy;
+    angleaxis_to_rotation(rotation + 3 * n, c.R);
+    c.t[0] = translation[3 * n]; c.t[1] = translation[3 * n + 1]; c.t[2] = translation[3 * n + 2];
+    return c;
+}
+
+// sops.depth_to_flow for one pixel (+ the |flow| < 1 / NaN gate of blocks_original.py:163-168 when gate != 0)
+__device__ __forceinline__ void depth_to_flow_pixel(const Camera &c, float d, int x, int y, int H, int W, int inverse_depth,
+                                                    int normalize_flow, int gate, float &fxo, float &fyo)
+{
+#pragma clang fp contract(off)  // same roundings wherever this is inlined (and as the oracle's plain C): see the header comment
+    fxo = __builtin_nanf("");
+    fyo = __builtin_nanf("");
+    if (inverse_depth) d = 1.0f / d;
+    if (d > 0.0f && isfinite(d)) {
+        const float px = x + 0.5f, py = y + 0.5f;
+        const float X = d * ((px - c.cx) * c.ifx), Y = d * ((py - c.cy) * c.ify), Z = d;
+        const float X2 = c.R[0] * X + c.R[1] * Y + c.R[2] * Z + c.t[0];
+        const float Y2 = c.R[3] * X + c.R[4] * Y + c.R[5] * Z + c.t[1];
+        const float Z2 = c.R[6] * X + c.R[7] * Y + c.R[8] * Z + c.t[2];
+        const float p2x = c.fx * X2 / Z2 + c.cx, p2y = c.fy * Y2 / Z2 + c.cy;
+        fxo = p2x - px;
+        fyo = p2y - py;
+        if (normalize_flow) { fxo /= W; fyo /= H; }
+    }
+    if (gate) {
+        const float nrm = sqrtf(fxo * fxo + fyo * fyo);
+        if (!(nrm < 1.0f)) { fxo = 0.0f; fyo = 0.0f; }
     }
 }
 
@@ -48,30 +95,9 @@ __global__ __launch_bounds__(256) void depth_to_flow_kernel(float *__restrict__ 
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= hw) return;
     const int y = idx / W, x = idx - y * W;
-    const float *K = intrinsics + 4 * n;
-    const float fx = K[0] * W, fy = K[1] * H, cx = K[2] * W, cy = K[3] * H;
-    const float ifx = 1.0f / fx, ify = 1.0f / fy;
-    float R[9];
-    angleaxis_to_rotation(rotation + 3 * n, R);
-    const float *t = translation + 3 * n;
-    float d = depth[(long)n * depth_n_stride + idx];
-    float fxo = __builtin_nanf(""), fyo = __builtin_nanf("");
-    if (inverse_depth) d = 1.0f / d;
-    if (d > 0.0f && isfinite(d)) {
-        const float px = x + 0.5f, py = y + 0.5f;
-        const float X = d * ((px - cx) * ifx), Y = d * ((py - cy) * ify), Z = d;
-        const float X2 = R[0] * X + R[1] * Y + R[2] * Z + t[0];
-        const float Y2 = R[3] * X + R[4] * Y + R[5] * Z + t[1];
-        const float Z2 = R[6] * X + R[7] * Y + R[8] * Z + t[2];
-        const float p2x = fx * X2 / Z2 + cx, p2y = fy * Y2 / Z2 + cy;
-        fxo = p2x - px;
-        fyo = p2y - py;
-        if (normalize_flow) { fxo /= W; fyo /= H; }
-    }
-    if (gate) {
-        const float nrm = sqrtf(fxo * fxo + fyo * fyo);
-        if (!(nrm < 1.0f)) { fxo = 0.0f; fyo = 0.0f; }
-    }
+    const Camera c = load_camera(intrinsics, rotation, translation, n, H, W);
+    float fxo, fyo;
+    depth_to_flow_pixel(c, depth[(long)n * depth_n_stride + idx], x, y, H, W, inverse_depth, normalize_flow, gate, fxo, fyo);
     float *o = out + (long)n * out_n_stride + idx;
     o[0] = fxo;
     o[hw] = fyo;
@@ -81,6 +107,7 @@ __global__ __launch_bounds__(256) void depth_to_flow_kernel(float *__restrict__ 
 // smallest singular value.  Same operation sequence as jacobi_null4 in oracle/demon_oracle.c.
 __device__ __forceinline__ void jacobi_null4(float A[4][4], float X[4])
 {
+#pragma clang fp contract(off)  // same roundings wherever this is inlined (and as the oracle's plain C): see the header comment
     float V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
     for (int sweep = 0; sweep < 8; ++sweep) {
 #pragma unroll
@@ -125,27 +152,13 @@ __device__ __forceinline__ void jacobi_null4(float A[4][4], float X[4])
     }
 }
 
-// grid: (ceil(H*W/256), N)
-__global__ __launch_bounds__(256) void flow_to_depth_kernel(float *__restrict__ out, long out_n_stride,
-                                                            const float *__restrict__ flow, long flow_n_stride,
-                                                            const float *__restrict__ intrinsics,
-                                                            const float *__restrict__ rotation,
-                                                            const float *__restrict__ translation, int H, int W,
-                                                            int inverse_depth, int normalized_flow, int method,
-                                                            float clip_hi)
+// sops.flow_to_depth (method 0: DLT / SVD) / flow_to_depth2 (method 1: closed form) for one pixel
+__device__ __forceinline__ float flow_to_depth_pixel(const Camera &c, float u, float v, int x, int y, int H, int W, int inverse_depth,
+                                                     int normalized_flow, int method, float clip_hi)
 {
-    const int n = blockIdx.y;
-    const int hw = H * W;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= hw) return;
-    const int y = idx / W, x = idx - y * W;
-    const float *K = intrinsics + 4 * n;
-    const float fx = K[0] * W, fy = K[1] * H, cx = K[2] * W, cy = K[3] * H;
-    float R[9];
-    angleaxis_to_rotation(rotation + 3 * n, R);
-    const float *t = translation + 3 * n;
-    float u = flow[(long)n * flow_n_stride + idx];
-    float v = flow[(long)n * flow_n_stride + hw + idx];
+#pragma clang fp contract(off)  // same roundings wherever this is inlined (and as the oracle's plain C): see the header comment
+    const float fx = c.fx, fy = c.fy, cx = c.cx, cy = c.cy;
+    const float *R = c.R, *t = c.t;
     if (normalized_flow) { u *= W; v *= H; }
     const float p1x = x + 0.5f, p1y = y + 0.5f;
     const float p2x = p1x + u, p2y = p1y + v;
@@ -185,11 +198,77 @@ __global__ __launch_bounds__(256) void flow_to_depth_kernel(float *__restrict__ 
     // v2/blocks.py:379 tf.clip_by_value(., 0, 50) fused here (clip_hi > 0): max(min(r, hi), 0) with fminf / fmaxf, i.e. the
     // semantics of TF's GPU kernels, the only backend the v2 driver accepts (example_v2.py:50-54): NaN -> hi
     if (clip_hi > 0.0f) r = fmaxf(fminf(r, clip_hi), 0.0f);
-    out[(long)n * out_n_stride + idx] = r;
+    return r;
 }
 
-// Backward bilinear warp, direct gather (default, see launch_warp2d).  grid: (ceil(H*W/256), N); each thread handles one
-// pixel for all C channels; the four taps of neighbouring lanes fall into the same or adjacent 128-byte lines.
+// grid: (ceil(H*W/256), N)
+__global__ __launch_bounds__(256) void flow_to_depth_kernel(float *__restrict__ out, long out_n_stride,
+                                                            const float *__restrict__ flow, long flow_n_stride,
+                                                            const float *__restrict__ intrinsics,
+                                                            const float *__restrict__ rotation,
+                                                            const float *__restrict__ translation, int H, int W,
+                                                            int inverse_depth, int normalized_flow, int method,
+                                                            float clip_hi)
+{
+    const int n = blockIdx.y;
+    const int hw = H * W;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw) return;
+    const int y = idx / W, x = idx - y * W;
+    const Camera c = load_camera(intrinsics, rotation, translation, n, H, W);
+    const float u = flow[(long)n * flow_n_stride + idx];
+    const float v = flow[(long)n * flow_n_stride + hw + idx];
+    out[(long)n * out_n_stride + idx] = flow_to_depth_pixel(c, u, v, x, y, H, W, inverse_depth, normalized_flow, method, clip_hi);
+}
+
+// sops.warp2d for one pixel: the four bilinear taps (clamped indices, inside flags, weights) decided once per pixel ...
+struct WarpTaps {
+    int xi[2], yi[2];
+    bool okx[2], oky[2], finite;
+    float w00, w01, w10, w11;
+};
+__device__ __forceinline__ WarpTaps warp_taps(float dx, float dy, int x, int y, int H, int W, int normalized)
+{
+#pragma clang fp contract(off)  // same roundings wherever this is inlined (and as the oracle's plain C): see the header comment
+    WarpTaps t;
+    if (normalized) { dx *= W; dy *= H; }
+    const float sx = x + dx, sy = y + dy;
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const float a = sx - fx0, b = sy - fy0;
+    t.finite = isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
+    const int x0 = t.finite ? (int)fx0 : -2, y0 = t.finite ? (int)fy0 : -2;
+    t.w00 = (1.0f - a) * (1.0f - b); t.w01 = a * (1.0f - b); t.w10 = (1.0f - a) * b; t.w11 = a * b;
+    t.xi[0] = x0; t.xi[1] = x0 + 1; t.yi[0] = y0; t.yi[1] = y0 + 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        t.okx[k] = t.xi[k] >= 0 && t.xi[k] < W;
+        t.oky[k] = t.yi[k] >= 0 && t.yi[k] < H;
+        t.xi[k] = min(max(t.xi[k], 0), W - 1);
+        t.yi[k] = min(max(t.yi[k], 0), H - 1);
+    }
+    return t;
+}
+// ... and applied to every channel plane p
+__device__ __forceinline__ float warp_plane(const WarpTaps &t, const float *__restrict__ p, int W, bool value_mode, float border_value)
+{
+#pragma clang fp contract(off)  // same roundings wherever this is inlined (and as the oracle's plain C): see the header comment
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int kx = k & 1, ky = k >> 1;
+        const float g = p[t.yi[ky] * W + t.xi[kx]];
+        v[k] = (value_mode && !(t.finite && t.okx[kx] && t.oky[ky])) ? border_value : g;
+    }
+    if (t.finite) return t.w00 * v[0] + t.w01 * v[1] + t.w10 * v[2] + t.w11 * v[3];
+    return value_mode ? border_value : __builtin_nanf("");
+}
+
+// Backward bilinear warp by direct gather.  grid: (ceil(H*W/256), N); each thread handles one pixel for all C channels; the four
+// taps of neighbouring lanes fall into the same or adjacent 128-byte lines.  The source planes (3 x 48 x 64 floats = 36 KB per
+// pair at 256x192, 230 KB at 640x480) sit in L1 / L2, which is why staging them through LDS does not pay: a staged variant
+// (4 x 64 output tile, block-reduced bounding box of the taps copied to LDS, direct-gather fallback for large or incoherent
+// displacements) measured 82-100 us against 18-25 us for this kernel on the 120 x 160 level-2 maps of the 640x480 workload
+// (batch 64, round 1) and was removed in round 2; at 48 x 64 either is bound by the launch.
 __global__ __launch_bounds__(256) void warp2d_kernel(float *__restrict__ out, long out_n_stride,
                                                      const float *__restrict__ in, long in_n_stride,
                                                      const float *__restrict__ disp, long disp_n_stride, int C,
@@ -201,122 +280,89 @@ __global__ __launch_bounds__(256) void warp2d_kernel(float *__restrict__ out, lo
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= hw) return;
     const int y = idx / W, x = idx - y * W;
-    float dx = disp[(long)n * disp_n_stride + idx];
-    float dy = disp[(long)n * disp_n_stride + hw + idx];
-    if (normalized) { dx *= W; dy *= H; }
-    const float sx = x + dx, sy = y + dy;
-    const float fx0 = floorf(sx), fy0 = floorf(sy);
-    const float a = sx - fx0, b = sy - fy0;
-    const bool finite = isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
-    const int x0 = finite ? (int)fx0 : -2, y0 = finite ? (int)fy0 : -2;
-    const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
-    int xi[2] = {x0, x0 + 1}, yi[2] = {y0, y0 + 1};
-    bool okx[2], oky[2];
+    const WarpTaps t = warp_taps(disp[(long)n * disp_n_stride + idx], disp[(long)n * disp_n_stride + hw + idx], x, y, H, W, normalized);
+    for (int c = 0; c < C; ++c)
+        out[(long)n * out_n_stride + (long)c * hw + idx] = warp_plane(t, in + (long)n * in_n_stride + (long)c * hw, W, border_mode == 1, border_value);
+}
+
+// ---- fused assembly of the extra inputs of the iterative blocks (one launch instead of three or four) ----------------------
+// Flow block (blocks_original.py:155-183; v2/blocks.py:154-183): extra = [image2_2 warped by the flow that the previous depth
+// and motion imply (3), that flow, gated (2), previous depth (1), previous normals (3)].  `dn` is the 4-channel depth+normal
+// buffer of the previous stage.  Same per-pixel functions as the stand-alone kernels, so the result is bit-identical.
+// grid: (ceil(H*W/256), N)
+__global__ __launch_bounds__(256) void assemble_flow_inputs_kernel(float *__restrict__ extra, long extra_n_stride,
+                                                                   const float *__restrict__ img2, long img2_n_stride,
+                                                                   const float *__restrict__ dn, long dn_n_stride,
+                                                                   const float *__restrict__ intrinsics, const float *__restrict__ rotation,
+                                                                   const float *__restrict__ translation, int H, int W)
+{
+    const int n = blockIdx.y;
+    const int hw = H * W;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw) return;
+    const int y = idx / W, x = idx - y * W;
+    const Camera c = load_camera(intrinsics, rotation, translation, n, H, W);
+    const float *__restrict__ d4 = dn + (long)n * dn_n_stride + idx;
+    const float d = d4[0];
+    float fx, fy;
+    depth_to_flow_pixel(c, d, x, y, H, W, 1, 1, 1, fx, fy);
+    float *__restrict__ o = extra + (long)n * extra_n_stride + idx;
+    const WarpTaps t = warp_taps(fx, fy, x, y, H, W, 1);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        okx[k] = xi[k] >= 0 && xi[k] < W;
-        oky[k] = yi[k] >= 0 && yi[k] < H;
-        xi[k] = min(max(xi[k], 0), W - 1);
-        yi[k] = min(max(yi[k], 0), H - 1);
-    }
-    const bool value_mode = border_mode == 1;
-    for (int c = 0; c < C; ++c) {
-        const float *p = in + (long)n * in_n_stride + (long)c * hw;
-        float v[4];
+    for (int ch = 0; ch < 3; ++ch) o[(long)ch * hw] = warp_plane(t, img2 + (long)n * img2_n_stride + (long)ch * hw, W, true, 0.0f);
+    o[3l * hw] = fx;
+    o[4l * hw] = fy;
+    o[5l * hw] = d;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int kx = k & 1, ky = k >> 1;
-            const float g = p[yi[ky] * W + xi[kx]];
-            v[k] = (value_mode && !(finite && okx[kx] && oky[ky])) ? border_value : g;
-        }
-        float r;
-        if (finite)
-            r = w00 * v[0] + w01 * v[1] + w10 * v[2] + w11 * v[3];
-        else
-            r = value_mode ? border_value : __builtin_nanf("");
-        out[(long)n * out_n_stride + (long)c * hw + idx] = r;
+    for (int ch = 0; ch < 3; ++ch) o[(long)(6 + ch) * hw] = d4[(long)(1 + ch) * hw];
+}
+
+// Depth+motion block (blocks_original.py:335-362; v2/blocks.py:353-381): extra = [image2_2 warped by the predicted flow (3),
+// flow + confidence (4), and in the iterative net the depth triangulated from that flow and the previous motion (1)].
+__global__ __launch_bounds__(256) void assemble_dm_inputs_kernel(float *__restrict__ extra, long extra_n_stride,
+                                                                 const float *__restrict__ img2, long img2_n_stride,
+                                                                 const float *__restrict__ flowconf, long fc_n_stride,
+                                                                 const float *__restrict__ intrinsics, const float *__restrict__ rotation,
+                                                                 const float *__restrict__ translation, int H, int W, int with_depth,
+                                                                 int method, float clip_hi)
+{
+    const int n = blockIdx.y;
+    const int hw = H * W;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw) return;
+    const int y = idx / W, x = idx - y * W;
+    const float *__restrict__ fc = flowconf + (long)n * fc_n_stride + idx;
+    const float u = fc[0], v = fc[hw];
+    float *__restrict__ o = extra + (long)n * extra_n_stride + idx;
+    const WarpTaps t = warp_taps(u, v, x, y, H, W, 1);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) o[(long)ch * hw] = warp_plane(t, img2 + (long)n * img2_n_stride + (long)ch * hw, W, true, 0.0f);
+    o[3l * hw] = u;
+    o[4l * hw] = v;
+    o[5l * hw] = fc[2l * hw];
+    o[6l * hw] = fc[3l * hw];
+    if (with_depth) {
+        const Camera c = load_camera(intrinsics, rotation, translation, n, H, W);
+        o[7l * hw] = flow_to_depth_pixel(c, u, v, x, y, H, W, 1, 1, method, clip_hi);
     }
 }
 
-// LDS-staged variant: a block owns a 4 x 64 output tile (one wavefront per 64-pixel row segment).  The block first
-// reduces the bounding box of all source taps it needs; when that box (tile + displacement halo) fits the LDS tile it
-// is copied once per channel with coalesced row loads and the four bilinear taps of every pixel are gathered from LDS;
-// otherwise (large or incoherent displacements) the block falls back to the direct global gather.
-// grid: (ceil(W/64), ceil(H/4), N)
-#define WARP_LDS_FLOATS 8192
-__global__ __launch_bounds__(256) void warp2d_lds_kernel(float *__restrict__ out, long out_n_stride,
-                                                         const float *__restrict__ in, long in_n_stride,
-                                                         const float *__restrict__ disp, long disp_n_stride, int C, int H,
-                                                         int W, int normalized, int border_mode, float border_value)
+// refinement net input (blocks_original.py:475-482): [image1 (3), depth2 upsampled x4 by nearest neighbour (1)] in one launch
+// grid: (ceil(H*W/256), N); H, W = full resolution
+__global__ __launch_bounds__(256) void assemble_refine_input_kernel(float *__restrict__ out, long out_n_stride,
+                                                                    const float *__restrict__ image, long image_n_stride,
+                                                                    const float *__restrict__ depth2, long depth_n_stride, int H, int W, int factor)
 {
-    __shared__ float tile[WARP_LDS_FLOATS];
-    __shared__ int bb[4];  // min x, max x, min y, max y of the (clamped) taps
-    const int n = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const bool inside = x < W && y < H;
+    const int n = blockIdx.y;
     const int hw = H * W;
-    const int idx = inside ? y * W + x : 0;
-    float dx = disp[(long)n * disp_n_stride + idx];
-    float dy = disp[(long)n * disp_n_stride + hw + idx];
-    if (normalized) { dx *= W; dy *= H; }
-    const float sx = x + dx, sy = y + dy;
-    const float fx0 = floorf(sx), fy0 = floorf(sy);
-    const float a = sx - fx0, b = sy - fy0;
-    const bool finite = isfinite(sx) && isfinite(sy) && fabsf(sx) < 1e9f && fabsf(sy) < 1e9f;
-    const int x0 = finite ? (int)fx0 : -2, y0 = finite ? (int)fy0 : -2;
-    const float w00 = (1.0f - a) * (1.0f - b), w01 = a * (1.0f - b), w10 = (1.0f - a) * b, w11 = a * b;
-    int xi[2] = {x0, x0 + 1}, yi[2] = {y0, y0 + 1};
-    bool okx[2], oky[2];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= hw) return;
+    const int y = idx / W, x = idx - y * W;
+    float *__restrict__ o = out + (long)n * out_n_stride + idx;
+    const float *__restrict__ im = image + (long)n * image_n_stride + idx;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        okx[k] = xi[k] >= 0 && xi[k] < W;
-        oky[k] = yi[k] >= 0 && yi[k] < H;
-        xi[k] = min(max(xi[k], 0), W - 1);
-        yi[k] = min(max(yi[k], 0), H - 1);
-    }
-    if (threadIdx.x == 0) { bb[0] = W; bb[1] = -1; bb[2] = H; bb[3] = -1; }
-    __syncthreads();
-    if (inside && finite) {
-        atomicMin(&bb[0], xi[0]); atomicMax(&bb[1], xi[1]);
-        atomicMin(&bb[2], yi[0]); atomicMax(&bb[3], yi[1]);
-    }
-    __syncthreads();
-    const int bx0 = bb[0], bx1 = bb[1], by0 = bb[2], by1 = bb[3];
-    const int rw = bx1 - bx0 + 1, rh = by1 - by0 + 1;
-    const bool staged = rw > 0 && rh > 0 && (long)rw * rh <= WARP_LDS_FLOATS;
-    const bool value_mode = border_mode == 1;
-    for (int c = 0; c < C; ++c) {
-        const float *p = in + (long)n * in_n_stride + (long)c * hw;
-        float v[4];
-        if (staged) {
-            __syncthreads();  // previous channel's gathers are done
-            for (int e = threadIdx.x; e < rw * rh; e += 256) {
-                const int ry = e / rw, rx = e - ry * rw;
-                tile[e] = p[(by0 + ry) * W + bx0 + rx];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int kx = k & 1, ky = k >> 1;
-                const float g = (inside && finite) ? tile[(yi[ky] - by0) * rw + (xi[kx] - bx0)] : 0.0f;
-                v[k] = (value_mode && !(finite && okx[kx] && oky[ky])) ? border_value : g;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int kx = k & 1, ky = k >> 1;
-                const float g = p[yi[ky] * W + xi[kx]];
-                v[k] = (value_mode && !(finite && okx[kx] && oky[ky])) ? border_value : g;
-            }
-        }
-        float r;
-        if (finite)
-            r = w00 * v[0] + w01 * v[1] + w10 * v[2] + w11 * v[3];
-        else
-            r = value_mode ? border_value : __builtin_nanf("");
-        if (inside) out[(long)n * out_n_stride + (long)c * hw + idx] = r;
-    }
+    for (int ch = 0; ch < 3; ++ch) o[(long)ch * hw] = im[(long)ch * hw];
+    o[3l * hw] = depth2[(long)n * depth_n_stride + (y / factor) * (W / factor) + (x / factor)];
 }
 
 __global__ __launch_bounds__(256) void leaky_relu_kernel(float *__restrict__ out, const float *__restrict__ in,
@@ -562,20 +608,35 @@ void launch_warp2d(float *out, long out_n_stride, const float *in, long in_n_str
                    long disp_n_stride, int N, int C, int H, int W, int normalized, int border_mode,
                    float border_value, hipStream_t s)
 {
-    // Measured on MI355X (640x480 level-2 maps, batch 64, the incoherent flow of random weights): direct gather 18-25 us,
-    // LDS-staged 82-100 us; at 48x64 both are launch bound.  The source planes (3 x 120 x 160 floats) are L1/L2 resident,
-    // so staging only pays for coherent flow on maps that do not cache-fit: direct gather is the default, DEMON_WARP_LDS=1
-    // selects the staged kernel (same results, covered by the tests).
-    static const bool use_lds = getenv("DEMON_WARP_LDS") && atoi(getenv("DEMON_WARP_LDS")) != 0;
-    if (use_lds) {
-        dim3 grid((W + 63) / 64, (H + 3) / 4, N);
-        hipLaunchKernelGGL(warp2d_lds_kernel, grid, dim3(256), 0, s, out, out_n_stride, in, in_n_stride, disp,
-                           disp_n_stride, C, H, W, normalized, border_mode, border_value);
-        return;
-    }
     dim3 grid((H * W + 255) / 256, N);
     hipLaunchKernelGGL(warp2d_kernel, grid, dim3(256), 0, s, out, out_n_stride, in, in_n_stride, disp, disp_n_stride, C,
                        H, W, normalized, border_mode, border_value);
+}
+
+void launch_assemble_flow_inputs(float *extra, long extra_n_stride, const float *img2, long img2_n_stride, const float *dn,
+                                 long dn_n_stride, const float *intrinsics, const float *rotation, const float *translation, int N, int H,
+                                 int W, hipStream_t s)
+{
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(assemble_flow_inputs_kernel, grid, dim3(256), 0, s, extra, extra_n_stride, img2, img2_n_stride, dn, dn_n_stride,
+                       intrinsics, rotation, translation, H, W);
+}
+
+void launch_assemble_dm_inputs(float *extra, long extra_n_stride, const float *img2, long img2_n_stride, const float *flowconf,
+                               long fc_n_stride, const float *intrinsics, const float *rotation, const float *translation, int N, int H,
+                               int W, int with_depth, int method, float clip_hi, hipStream_t s)
+{
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(assemble_dm_inputs_kernel, grid, dim3(256), 0, s, extra, extra_n_stride, img2, img2_n_stride, flowconf, fc_n_stride,
+                       intrinsics, rotation, translation, H, W, with_depth, method, clip_hi);
+}
+
+void launch_assemble_refine_input(float *out, long out_n_stride, const float *image, long image_n_stride, const float *depth2,
+                                  long depth_n_stride, int N, int H, int W, int factor, hipStream_t s)
+{
+    dim3 grid((H * W + 255) / 256, N);
+    hipLaunchKernelGGL(assemble_refine_input_kernel, grid, dim3(256), 0, s, out, out_n_stride, image, image_n_stride, depth2, depth_n_stride, H, W,
+                       factor);
 }
 
 void launch_leaky_relu(float *out, const float *in, long count, float leak, hipStream_t s)

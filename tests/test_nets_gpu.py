@@ -335,3 +335,43 @@ def test_fused_pairs_all_types_in_subprocess(tmp_path):
     env = dict(os.environ, DEMON_FUSED_PAIRS_ALL="1")
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "fused ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_fused_input_assembly_is_exact(gpu_ctx):
+    """one-launch assembly of the extra inputs (depth_to_flow + gate + warp2d + concat; warp2d + concat + flow_to_depth; image +
+    upsampled depth, blocks_original.py:155-183, :335-362, :475-482) == the chain of stand-alone op launches, bit for bit, with
+    both flow_to_depth formulations, graph and eager, side branches on and off; gate-stress weights (NaN / zeroed flows) too"""
+    from demon_amd import weights
+    pair, img2_2 = make_inputs(3, seed=21)
+    results = {}
+    try:
+        for method in (0, 1):
+            gpu_ctx.set_option("flow_to_depth_method", method)
+            for fused in (1, 0):
+                for side, graph in ((1, 1), (0, 0)):
+                    gpu_ctx.set_option("fused_inputs", fused)
+                    gpu_ctx.set_option("side_branches", side)
+                    gpu_ctx.set_option("hipgraph", graph)
+                    results[(method, fused, side, graph)] = gpu_ctx.full(pair, img2_2, iterations=3)
+    finally:
+        for k, v in (("fused_inputs", 1), ("side_branches", 1), ("hipgraph", 1), ("flow_to_depth_method", 0)):
+            gpu_ctx.set_option(k, v)
+    for method in (0, 1):
+        ref = results[(method, 0, 0, 0)]
+        for key, got in results.items():
+            if key[0] != method:
+                continue
+            for k in KEYS + ("predict_depth0",):
+                np.testing.assert_array_equal(got[k], ref[k], err_msg="%s %s" % (key, k))
+    assert not np.array_equal(results[(0, 1, 1, 1)]["predict_depth2"], results[(1, 1, 1, 1)]["predict_depth2"])   # the option is live
+    from demon_amd import DemonContext
+    ctx = DemonContext(0, 2, 192, 256)
+    try:
+        ctx.set_weights(weights.synthetic_weights(seed=2, head_scale=1.0))    # gate stress: large flows, invalid depths
+        a = ctx.full(pair[:2], img2_2[:2], iterations=2)
+        ctx.set_option("fused_inputs", 0)
+        b = ctx.full(pair[:2], img2_2[:2], iterations=2)
+        for k in KEYS + ("predict_depth0",):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    finally:
+        ctx.close()

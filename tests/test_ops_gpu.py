@@ -223,40 +223,6 @@ def test_sops_module_mirror(gpu_ctx, synth_weights):
     assert sops._ctx().max_batch == 0      # the module runs on an op-only context (no network arena behind an elementwise op)
 
 
-def test_warp2d_lds_staged_variant_matches(tmp_path):
-    """the LDS-staged warp2d kernel (DEMON_WARP_LDS=1, read once per process) gives the same results as the oracle for
-    coherent flow (staged path) and for wild flow (its direct-gather fallback)"""
-    import subprocess
-    import sys
-    import os
-    code = r'''
-import sys, os
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
-from demon_amd import DemonContext
-from oracle import ops_ref
-ctx = DemonContext(0, 1)
-rng = np.random.default_rng(50)
-for shape, amp in (((2, 3, 48, 64), 0.02), ((2, 3, 120, 160), 0.01), ((1, 2, 37, 53), 3.0), ((1, 3, 48, 64), 0.6)):
-    n, c, h, w = shape
-    img = rng.random(shape).astype(np.float32)
-    for normalized, border in ((True, "value"), (False, "clamp")):
-        disp = (rng.standard_normal((n, 2, h, w)) * (amp if normalized else amp * 60)).astype(np.float32)
-        disp[0, 0, 0, 0] = np.nan
-        want = ops_ref.warp2d(img, disp, normalized, border, 0.5)
-        got = ctx.warp2d(img, disp, normalized, border, 0.5)
-        assert np.array_equal(np.isnan(got), np.isnan(want))
-        m = ~np.isnan(want)
-        assert np.abs(got[m] - want[m]).max() < 1e-4, (shape, normalized, border)
-print("ok")
-'''
-    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    code = "ROOT = %r\n" % root + code
-    env = dict(os.environ, DEMON_WARP_LDS="1")
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
-
-
 @pytest.mark.parametrize("shape", [(2, 2, 48, 64), (3, 1, 17, 33), (1, 3, 192, 256)])
 def test_pointwise_l2_loss(gpu_ctx, shape):
     """HIP pointwise_l2_loss (v2/losses.py:33-54) == the numpy restatement, with NaN / inf pixels in prediction and ground truth"""
