@@ -64,13 +64,17 @@ struct StreamSet {
 
 // NW waves stacked along Cout (BM = 32 * TM * NW), a wave owns 32*TM channels x 32*TN pixels: TM*TN accumulator blocks, and per
 // K-step 8*TM*TN MFMAs on 2*TM 16-byte + 8*TN 4-byte loads (512 / 384 / 256 operand bytes per MFMA for 1x1 / 1x2 / 2x2).
-template <int NW, int TM, int TN>
-__global__ __launch_bounds__(64 * NW) void conv_stream_kernel(StreamArgs s)
+// KW > 1 (small batches: few output tiles, long K): KW groups of NW waves share the tile and split its K range between them;
+// their partial accumulators are summed through LDS at the end, in wave order -- split-K without partial sums in HBM and
+// without a reduce launch.
+template <int NW, int TM, int TN, int KW>
+__global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
 {
     const ConvArgs &a = s.c;
     TlScope tl(a.tl);
     constexpr int BM = 32 * TM * NW, BN = 32 * TN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (tid >> 6) % NW, wk = (tid >> 6) / NW;  // position along Cout / K slice inside the workgroup
     const int l31 = lane & 31, lhi = lane >> 5;
     const int cls = blockIdx.z / a.ksplit;
     const int zs = blockIdx.z - cls * a.ksplit;
@@ -105,8 +109,13 @@ __global__ __launch_bounds__(64 * NW) void conv_stream_kernel(StreamArgs s)
 
     // ---- K range of this slice, in steps of 16 reduction indices
     const int per_slice = (s.nsteps + a.ksplit - 1) / a.ksplit;
-    const int s_begin = zs * per_slice;
-    const int s_end = min(s.nsteps, s_begin + per_slice);
+    int s_begin = zs * per_slice;
+    int s_end = min(s.nsteps, s_begin + per_slice);
+    if (KW > 1) {  // this wave group's share of the workgroup's K range
+        const int per_wave = (max(s_end - s_begin, 0) + KW - 1) / KW;
+        s_begin += wk * per_wave;
+        s_end = min(s_end, s_begin + per_wave);
+    }
     const long a_step = (long)(a.Mpad >> 5) * 512;  // floats between consecutive steps of Wf
     const float *__restrict__ wf = s.wf + cls * s.cls_wf_stride + (long)s_begin * a_step + ((long)(m0 >> 5) * 64 + lane) * 8;
 
@@ -209,6 +218,36 @@ __global__ __launch_bounds__(64 * NW) void conv_stream_kernel(StreamArgs s)
     }
     tl.mark(2);
 
+    if constexpr (KW > 1) {
+        // sum the KW partial tiles through LDS: every group parks its accumulators, then group g adds up the registers
+        // r = g, g + KW, ... of all groups IN GROUP ORDER (results do not depend on timing) and hands the sums to group 0,
+        // which runs the epilogue alone.  Two barriers, R + R / KW LDS reads per lane.
+        constexpr int R = TM * TN * 16;
+        extern __shared__ __attribute__((aligned(16))) float red[];   // [KW][NW][R][64]
+        float *base = red + (long)wave * (R * 64) + lane;
+        float *mine = base + (long)wk * (NW * R * 64);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+        __syncthreads();
+        for (int r = wk; r < R; r += KW) {
+            float sum = base[r * 64];
+            for (int g = 1; g < KW; ++g) sum += base[(long)g * (NW * R * 64) + r * 64];
+            base[r * 64] = sum;   // group 0's copy of register r (only this group touches register r now)
+        }
+        __syncthreads();
+        if (wk != 0) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = base[((i * TN + j) * 16 + r) * 64];
+    }
+
     // ---- epilogue (as conv_mfma.hip)
     if (a.ksplit > 1) {
         float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
@@ -298,19 +337,22 @@ __global__ __launch_bounds__(64 * NW) void conv_stream_kernel(StreamArgs s)
     }
 }
 
-struct StreamVariant { int nw, tm, tn; };
-// (waves along Cout, 32-channel row blocks per wave, 32-pixel column blocks per wave)
-static const StreamVariant kStreamVariants[STREAM_VARIANTS] = {{4, 1, 1}, {4, 1, 2}, {2, 1, 1}, {2, 1, 2}, {1, 1, 1}, {1, 1, 2},
-                                                               {2, 2, 2}, {1, 2, 2}, {2, 2, 1}, {4, 2, 1}};
+struct StreamVariant { int nw, tm, tn, kw; };
+// (waves along Cout, 32-channel row blocks per wave, 32-pixel column blocks per wave, K-splitting wave groups per workgroup)
+static const StreamVariant kStreamVariants[STREAM_VARIANTS] = {
+    {4, 1, 1, 1}, {4, 1, 2, 1}, {2, 1, 1, 1}, {2, 1, 2, 1}, {1, 1, 1, 1}, {1, 1, 2, 1}, {2, 2, 2, 1}, {1, 2, 2, 1}, {2, 2, 1, 1}, {4, 2, 1, 1},
+    {1, 1, 1, 4}, {1, 1, 1, 8}, {1, 1, 1, 16}, {1, 1, 2, 8}, {1, 2, 1, 8}, {1, 2, 2, 4}, {1, 2, 2, 8}, {2, 1, 1, 4}};
 
 int stream_variant_bm(int v) { return 32 * kStreamVariants[v].nw * kStreamVariants[v].tm; }
 int stream_variant_bn(int v) { return 32 * kStreamVariants[v].tn; }
-int stream_variant_waves(int v) { return kStreamVariants[v].nw; }
+int stream_variant_waves(int v) { return kStreamVariants[v].nw * kStreamVariants[v].kw; }
+int stream_variant_kw(int v) { return kStreamVariants[v].kw; }
 
-template <int NW, int TM, int TN>
+template <int NW, int TM, int TN, int KW>
 static void launch_stream_variant(const StreamArgs &s, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN>), grid, dim3(64 * NW), 0, stream, s);
+    const size_t lds = KW > 1 ? sizeof(float) * KW * NW * TM * TN * 16 * 64 : 0;
+    hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW>), grid, dim3(64 * NW * KW), lds, stream, s);
 }
 
 void launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
@@ -322,16 +364,24 @@ void launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int ncl
     const int bm = stream_variant_bm(variant), bn = stream_variant_bn(variant);
     dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)(a.Mpad / bm), (unsigned)(nclasses * ksplit));
     switch (variant) {
-        case 0: launch_stream_variant<4, 1, 1>(s, grid, stream); break;
-        case 1: launch_stream_variant<4, 1, 2>(s, grid, stream); break;
-        case 2: launch_stream_variant<2, 1, 1>(s, grid, stream); break;
-        case 3: launch_stream_variant<2, 1, 2>(s, grid, stream); break;
-        case 4: launch_stream_variant<1, 1, 1>(s, grid, stream); break;
-        case 5: launch_stream_variant<1, 1, 2>(s, grid, stream); break;
-        case 6: launch_stream_variant<2, 2, 2>(s, grid, stream); break;
-        case 7: launch_stream_variant<1, 2, 2>(s, grid, stream); break;
-        case 8: launch_stream_variant<2, 2, 1>(s, grid, stream); break;
-        default: launch_stream_variant<4, 2, 1>(s, grid, stream); break;
+        case 0: launch_stream_variant<4, 1, 1, 1>(s, grid, stream); break;
+        case 1: launch_stream_variant<4, 1, 2, 1>(s, grid, stream); break;
+        case 2: launch_stream_variant<2, 1, 1, 1>(s, grid, stream); break;
+        case 3: launch_stream_variant<2, 1, 2, 1>(s, grid, stream); break;
+        case 4: launch_stream_variant<1, 1, 1, 1>(s, grid, stream); break;
+        case 5: launch_stream_variant<1, 1, 2, 1>(s, grid, stream); break;
+        case 6: launch_stream_variant<2, 2, 2, 1>(s, grid, stream); break;
+        case 7: launch_stream_variant<1, 2, 2, 1>(s, grid, stream); break;
+        case 8: launch_stream_variant<2, 2, 1, 1>(s, grid, stream); break;
+        case 9: launch_stream_variant<4, 2, 1, 1>(s, grid, stream); break;
+        case 10: launch_stream_variant<1, 1, 1, 4>(s, grid, stream); break;
+        case 11: launch_stream_variant<1, 1, 1, 8>(s, grid, stream); break;
+        case 12: launch_stream_variant<1, 1, 1, 16>(s, grid, stream); break;
+        case 13: launch_stream_variant<1, 1, 2, 8>(s, grid, stream); break;
+        case 14: launch_stream_variant<1, 2, 1, 8>(s, grid, stream); break;
+        case 15: launch_stream_variant<1, 2, 2, 4>(s, grid, stream); break;
+        case 16: launch_stream_variant<1, 2, 2, 8>(s, grid, stream); break;
+        default: launch_stream_variant<2, 1, 1, 4>(s, grid, stream); break;
     }
     if (ksplit > 1) launch_splitk_reduce(s.c, nclasses, stream);
 }

@@ -699,9 +699,11 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
             if (L->Mpad % stream_variant_bm(v)) continue;
             const long wgs = (long)(L->Mpad / stream_variant_bm(v)) * ((P + stream_variant_bn(v) - 1) / stream_variant_bn(v)) * L->ncls;
             const long waves = wgs * stream_variant_waves(v);
+            const int kw = stream_variant_kw(v);
             for (int ks : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48}) {
                 if (ks > 1 && (ks > nsteps / 3 || (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
-                if (waves * ks < 512 || waves * ks > 16384) continue;  // at least half a wave per SIMD, at most 16
+                if (kw > 1 && (ks > 2 || nsteps < 2 * kw * ks)) continue;  // in-workgroup split-K is there to AVOID the reduce launch
+                if (waves * ks < (kw > 1 ? 128 : 512) || waves * ks > 16384) continue;  // enough waves to matter, at most 16 per SIMD
                 cands.push_back({4, v, ks});
             }
         }

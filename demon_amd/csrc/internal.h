@@ -133,8 +133,9 @@ struct StreamArgs {
     int tapdy[4][9], tapdx[4][9];  // per class and tap: input offset relative to the anchor pixel
     int dbg;               // diagnostic builds (-DDEMON_STREAM_DBG): bit 0 skip the A loads, bit 1 skip the B loads
 };
-constexpr int STREAM_VARIANTS = 10;  // (waves along Cout, row blocks per wave, column blocks per wave), see conv_stream.hip
+constexpr int STREAM_VARIANTS = 18;  // (waves along Cout, row blocks per wave, column blocks per wave), see conv_stream.hip
 int stream_variant_waves(int v);
+int stream_variant_kw(int v);  // K-splitting wave groups inside a workgroup (1: none)
 int stream_variant_bm(int v);
 int stream_variant_bn(int v);
 void launch_stream_repack(float *wf, const float *wp, int ncls, int K, int Mpad, long cls_w_stride, hipStream_t s);

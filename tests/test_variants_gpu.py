@@ -50,7 +50,7 @@ def test_all_variants_agree(gpu_ctx, layer):
     b = rng.standard_normal((cout,)).astype(np.float32)
     want = _ref(kind, x, w, b, (sh, sw))
     plans = [(3, 0, 0)] + [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(9) for ks in (0, 2, 3, 5)]
-    plans += [(4, v, ks) for v in range(10) for ks in (1, 2, 3, 5)]   # register-streaming kernel (applies when Cin % 16 == 0)
+    plans += [(4, v, ks) for v in range(18) for ks in (1, 2, 3, 5)]   # register-streaming kernel (applies when Cin % 16 == 0)
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
@@ -71,7 +71,7 @@ def test_streaming_kernel_is_bit_identical_to_im2col_and_runs_dense(gpu_ctx):
     try:
         os.environ["DEMON_FORCE_PLAN"] = "0,6,1"
         ref = gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True)
-        for v in range(10):
+        for v in range(10):   # variants without in-workgroup split-K keep the im2col summation order
             os.environ["DEMON_FORCE_PLAN"] = "4,%d,1" % v
             np.testing.assert_array_equal(gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True), ref)
         xd = rng.standard_normal((7, 6144)).astype(np.float32)
@@ -79,7 +79,7 @@ def test_streaming_kernel_is_bit_identical_to_im2col_and_runs_dense(gpu_ctx):
         bd = rng.standard_normal(1024).astype(np.float32)
         want = xd.astype(np.float64) @ wd.astype(np.float64) + bd
         want = np.where(want >= 0, want, 0.1 * want)
-        for plan in ("4,0,1", "4,0,8", "4,4,48", "4,2,16"):
+        for plan in ("4,0,1", "4,0,8", "4,4,48", "4,2,16", "4,12,1", "4,11,2", "4,16,1"):
             os.environ["DEMON_FORCE_PLAN"] = plan
             assert rel_l1(gpu_ctx.dense(xd, wd, bd, lrelu=True), want) < 1e-5, plan
     finally:
