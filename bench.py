@@ -101,6 +101,10 @@ def rocprof_kernel_name(tag):
         return "demon::conv_patch_kernel<%s, ...> (%sx%s tile, %s taps)" % (dims[0], dims[0], dims[1], rest.rstrip(">").split(",t")[-1])
     if fam == "deconv4":
         return "demon::deconv4_kernel<%s, ...>" % dims[0]
+    if fam == "conv_stream" and len(dims) == 2:
+        w, k = rest.rstrip(">").split(",")[1].lstrip("w").split("k")
+        tm = int(dims[0]) // (32 * int(w))
+        return "demon::conv_stream_kernel<%s, %d, %d, %s> (%sx%s tile)" % (w, tm, int(dims[1]) // 32, k, dims[0], dims[1])
     return "demon::%s_kernel" % fam
 
 

@@ -12,12 +12,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 
 
 def csrc_sha():
-    """sha1 over the kernel sources: stamps profiles (tools/pmc_summary.py) so that bench.py can tell a counter summary
-    measured on these kernels from a stale one"""
+    """sha1 over the kernel sources (every .hip except the host-side demon_api.hip, plus internal.h) and the shipped launch
+    plans: stamps profiles (tools/pmc_summary.py) so that bench.py can tell a counter summary measured on these kernels and
+    plans from a stale one"""
+    import glob
     import hashlib
     h = hashlib.sha1()
-    for name in sorted(SOURCES) + ["internal.h"]:
-        with open(os.path.join(CSRC, name), "rb") as f:
+    files = [os.path.join(CSRC, n) for n in sorted(SOURCES) if n != "demon_api.hip"] + [os.path.join(CSRC, "internal.h")]
+    files += sorted(glob.glob(os.path.join(HERE, "tuned", "*.json")))
+    for path in files:
+        with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
@@ -65,9 +69,7 @@ def build(force=False, verbose=False, extra_flags=(), tag=""):
 
 
 if __name__ == "__main__":
-    if "--pipe-mid" in sys.argv:
-        print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_PIPE_MID"], tag="mid"))
-    elif "--dbg" in sys.argv:
+    if "--dbg" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_STREAM_DBG"], tag="dbg"))
     elif "--timeline" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_TIMELINE"], tag="tl"))

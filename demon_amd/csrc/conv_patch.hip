@@ -421,11 +421,15 @@ __global__ __launch_bounds__(64 * WM * WN) void deconv4_kernel(PatchArgs a)
             oklast |= ((ok && last_c0 + c < a.Cin) ? 1u : 0u) << i;
         }
     }
+    const int dummy_off = 2 * 4 * KD * BM + 2 * patch_floats + 4 * tid;  // floats from smem: this thread's 16-byte dummy slot
+#pragma unroll
+    for (int i = 1; i < EPT; ++i)
+        if (!((wrbits >> i) & 1u)) goff[i] = goff[0];
     // A loader: chunk q of the [cls][KD][BM/4] tiles; row r = tap*CKS + cl  <->  packed row tap*Cin + c0 + cl of class cls
     long aoff[APER];
 #pragma unroll
     for (int i = 0; i < APER; ++i) {
-        const int q = tid + i * NT;
+        const int q = min(tid + i * NT, A4 - 1);
         const int cls = q / (KD * BM / 4), qq = q - cls * (KD * BM / 4);
         const int r = qq / (BM / 4), c4 = qq - r * (BM / 4);
         aoff[i] = (long)cls * a.cls_w_stride + (long)((r / CKS) * a.Cin + (r % CKS)) * a.Mpad + m0 + c4 * 4;
@@ -450,21 +454,18 @@ __global__ __launch_bounds__(64 * WM * WN) void deconv4_kernel(PatchArgs a)
 
     float pregA[EPT], pregB[EPT];
     floatx4 aregA[APER], aregB[APER];
-    auto load_patch_one = [&](float (&preg)[EPT], int i, const float *__restrict__ base) {
-        if ((wrbits >> i) & 1u) preg[i] = base[goff[i]];
-    };
+    // branch-free staging as in conv_patch_kernel: slots past the end re-load the thread's element 0 and land in a private dummy slot
+    auto load_patch_one = [&](float (&preg)[EPT], int i, const float *__restrict__ base) { preg[i] = base[goff[i]]; };
     auto load_a_one = [&](floatx4 (&areg)[APER], int i, const float *__restrict__ base) {
-        if (A4 % NT == 0 || tid + i * NT < A4) areg[i] = *reinterpret_cast<const floatx4 *>(base + aoff[i]);
+        areg[i] = *reinterpret_cast<const floatx4 *>(base + aoff[i]);
     };
     auto store_tiles = [&](const float (&preg)[EPT], const floatx4 (&areg)[APER], int buf, unsigned ok) {
-        float *P = Ps + buf * patch_floats;
 #pragma unroll
         for (int i = 0; i < EPT; ++i)
-            if ((wrbits >> i) & 1u) P[loff[i]] = ((ok >> i) & 1u) ? preg[i] : 0.0f;
-        float *A = As + buf * (4 * KD * BM);
+            smem[((wrbits >> i) & 1u) ? 2 * 4 * KD * BM + buf * patch_floats + loff[i] : dummy_off] = ((ok >> i) & 1u) ? preg[i] : 0.0f;
 #pragma unroll
         for (int i = 0; i < APER; ++i)
-            if (A4 % NT == 0 || tid + i * NT < A4) *reinterpret_cast<floatx4 *>(A + (tid + i * NT) * 4) = areg[i];
+            *reinterpret_cast<floatx4 *>(smem + ((A4 % NT == 0 || tid + i * NT < A4) ? buf * (4 * KD * BM) + (tid + i * NT) * 4 : dummy_off)) = areg[i];
     };
     auto kstep = [&](int buf, int next, float (&preg)[EPT], floatx4 (&areg)[APER], auto prefetch) {
         constexpr bool PREFETCH = decltype(prefetch)::value;
@@ -610,7 +611,7 @@ size_t patch_lds_bytes(int tile, int ntaps, int G, int PS)
 {
     const int cks = patch_cks(ntaps, tile);
     const size_t a_tiles = patch_tile_is_dc4(tile) ? 4 : 1;  // the fused transposed conv stages the weights of its four classes
-    // + one 16-byte dummy slot per thread (conv_patch_kernel's branch-free staging; the fused transposed conv does not use it)
+    // + one 16-byte dummy slot per thread (branch-free staging)
     return sizeof(float) * (2ul * a_tiles * ntaps * cks * kPatchTiles[tile].bm + 2ul * G * cks * PS + 4ul * kPatchTiles[tile].threads);
 }
 

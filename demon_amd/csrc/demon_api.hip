@@ -572,7 +572,10 @@ void run_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipS
     if (ksplit < 1) ksplit = 1;
     if (ksplit > sa.nsteps) ksplit = sa.nsteps;
     launch_conv_stream(sa, variant, ksplit, L->ncls, s);
-    set_kernel_tag("conv_stream", stream_variant_bm(variant), stream_variant_bn(variant), 0, ksplit > 1);
+    // e.g. "conv_stream<256x32,w4k1>": tile, waves along Cout x K-splitting wave groups (rocprofv3: conv_stream_kernel<NW, TM, TN, KW>)
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_stream<%dx%d,w%dk%d>%s", stream_variant_bm(variant), stream_variant_bn(variant),
+             stream_variant_waves(variant) / stream_variant_kw(variant), stream_variant_kw(variant), ksplit > 1 ? "+splitk" : "");
+    g_last_kernel = g_kernel_tag;
 }
 
 void run_mfma(const ConvArgs &a, ConvPlan plan, int ncls, hipStream_t s)
@@ -1195,9 +1198,33 @@ bool weights_ready(demon_ctx *c, std::string *missing)
 
 // mode 0: plain (every layer, no cache traffic); 1: first iteration with the option on (layers + save); 2: later iterations
 // (cached conv2 output instead of the image-only layers)
+// fork / join events: one per use inside a sequence (a captured event must not be re-recorded), created on demand so that any
+// iteration count fits; a failed creation or record / wait turns the side branches off for the rest of the sequence and is
+// reported by the caller (c->err)
+hipEvent_t next_event(demon_ctx *c, size_t &ev)
+{
+    if (ev >= c->events.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        c->events.push_back(e);
+    }
+    hipEvent_t e = c->events[ev];
+    if (e) ++ev;
+    return e;
+}
+
+// dst waits for everything enqueued on src so far; false (and an error note) when an event call fails
+bool stream_wait(demon_ctx *c, hipStream_t src, hipStream_t dst, size_t &ev)
+{
+    hipEvent_t e = next_event(c, ev);
+    if (e && hipEventRecord(e, src) == hipSuccess && hipStreamWaitEvent(dst, e, 0) == hipSuccess) return true;
+    if (c->err.empty()) c->err = "fork / join event of the side stream failed";
+    return false;
+}
+
 void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t s, int mode, size_t &ev)
 {
-    const bool branches = c->opt_side_branches && c->side_stream && s == c->stream;
+    bool branches = c->opt_side_branches && c->side_stream && s == c->stream;
     bool side_open = false;  // work on the side stream that the main stream has not waited for yet
     for (const Step &st : steps) {
         if (st.image_only == 1 && mode == 2) continue;
@@ -1206,25 +1233,18 @@ void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t 
         if ((st.pair == 1 && !c->opt_fused_pairs) || (st.pair == 2 && c->opt_fused_pairs)) continue;
         if ((st.fused == 1 && !c->opt_fused_inputs) || (st.fused == 2 && c->opt_fused_inputs)) continue;
         if (!branches) { st.fn(n, s); continue; }
-        if (st.fork && ev < c->events.size()) {
-            hipEventRecord(c->events[ev], s);
-            hipStreamWaitEvent(c->side_stream, c->events[ev], 0);
-            ++ev;
-            side_open = true;
+        if (st.fork) {
+            if (stream_wait(c, s, c->side_stream, ev)) side_open = true;
+            else if (!side_open) branches = false;  // nothing pending on the side stream: carry on single-stream
         }
-        if (st.join && side_open && ev < c->events.size()) {
-            hipEventRecord(c->events[ev], c->side_stream);
-            hipStreamWaitEvent(s, c->events[ev], 0);
-            ++ev;
-            side_open = false;
+        if (st.join && side_open) {
+            // a failed join would leave the side work unordered: fall back to a full wait outside a capture is impossible
+            // here, so the error is kept in c->err and surfaces through run_sequence
+            if (stream_wait(c, c->side_stream, s, ev)) side_open = false;
         }
         st.fn(n, (st.side && side_open) ? c->side_stream : s);
     }
-    if (side_open && ev < c->events.size()) {  // never leave the side stream dangling (a capture must be joined)
-        hipEventRecord(c->events[ev], c->side_stream);
-        hipStreamWaitEvent(s, c->events[ev], 0);
-        ++ev;
-    }
+    if (side_open) stream_wait(c, c->side_stream, s, ev);  // never leave the side stream dangling (a capture must be joined)
 }
 
 enum SeqKind { SEQ_BOOT = 0, SEQ_ITER, SEQ_REFINE, SEQ_FULL };
@@ -1242,10 +1262,11 @@ void enqueue_sequence(demon_ctx *c, int kind, int n, int iterations, hipStream_t
 // one hipGraph per (sequence, batch, iterations): the whole kernel chain becomes a single launch
 int run_sequence(demon_ctx *c, int kind, int n, int iterations)
 {
+    c->err.clear();
     if (!c->opt_hipgraph) {
         enqueue_sequence(c, kind, n, iterations, c->stream);
         HIP_TRY(c, hipGetLastError());
-        return DEMON_OK;
+        return c->err.empty() ? DEMON_OK : DEMON_ERR_HIP;
     }
     char key[64];
     snprintf(key, sizeof key, "%d:%d:%d:%d:%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method, c->opt_reuse_image, c->opt_side_branches,
@@ -1257,6 +1278,7 @@ int run_sequence(demon_ctx *c, int kind, int n, int iterations)
         HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         enqueue_sequence(c, kind, n, iterations, c->stream);
         HIP_TRY(c, hipStreamEndCapture(c->stream, &graph));
+        if (!c->err.empty()) { hipGraphDestroy(graph); return DEMON_ERR_HIP; }
         HIP_TRY(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         hipGraphDestroy(graph);
         it = c->graphs.emplace(key, exec).first;
@@ -1373,9 +1395,7 @@ static int create_impl(demon_ctx **out, int device, int max_batch, int height, i
     p->d_ws = dev_alloc(p, sizeof(float) * kSplitKWorkspaceFloats);
     p->d_ws_side = dev_alloc(p, sizeof(float) * kSplitKWorkspaceFloats);
     if (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess) p->side_stream = nullptr;
-    p->events.resize(256);  // 4 per pass of the flow + depth/motion blocks; a 30-iteration sequence still fits
-    for (hipEvent_t &e : p->events)
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; }
+    p->events.clear();  // fork / join events are created on demand (next_event)
     if (!p->d_ws_side) p->d_ws_side = p->d_ws, p->opt_side_branches = 0;
     if (!p->d_ws || !p->d_rot || !p->d_trans || !p->d_scale || !p->d_motion || !p->d_intrinsics) {
         demon_destroy(c.release());

@@ -91,6 +91,8 @@ def _parse_entry(value):
             e["offset"] = v
         elif field == 5:
             e["size"] = v
+        elif field == 6:
+            e["crc32c"] = v   # masked crc32c of the tensor bytes (fixed32); TensorFlow's BundleReader verifies it
         elif field == 7:
             raise ValueError("sliced (partitioned) variables are not supported")
     return e
@@ -146,7 +148,7 @@ def read_index(prefix):
     return out, num_shards
 
 
-def load_tf_checkpoint(prefix, names=None):
+def load_tf_checkpoint(prefix, names=None, verify_crc=True):
     """Reads the float variables of a TF checkpoint: dict name -> numpy array (TF layout).  `names` restricts /
     validates the set (KeyError when one is missing); optimizer slots etc. are otherwise returned too."""
     index, num_shards = read_index(prefix)
@@ -172,6 +174,8 @@ def load_tf_checkpoint(prefix, names=None):
             count = int(np.prod(e["shape"])) if e["shape"] else 1
             if len(raw) != e["size"] or e["size"] != count * dt.itemsize:
                 raise ValueError("variable %s: size mismatch in data file" % name)
+            if verify_crc and "crc32c" in e and _mask_crc(crc32c(raw)) != e["crc32c"]:
+                raise ValueError("variable %s: checksum does not match (data file corrupt)" % name)
             out[name] = np.frombuffer(raw, dtype=dt.newbyteorder("<")).reshape(e["shape"]).astype(dt)
     finally:
         for f in files.values():
@@ -185,22 +189,74 @@ def _mask_crc(crc):
 
 
 _CRC_TABLE = None
+_CRC_CHUNK = 4096
+_CRC_ZERO_TABLES = None   # the operator "append _CRC_CHUNK zero bytes" on the raw crc register, as 4 x 256 lookup tables
 
 
-def _crc32c(data):
+def _crc_table():
     global _CRC_TABLE
     if _CRC_TABLE is None:
-        tbl = []
+        tbl = np.zeros(256, np.uint32)
         for i in range(256):
             c = i
             for _ in range(8):
                 c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
-            tbl.append(c)
+            tbl[i] = c
         _CRC_TABLE = tbl
-    crc = 0xFFFFFFFF
-    for b in data:
-        crc = _CRC_TABLE[(crc ^ b) & 0xFF] ^ (crc >> 8)
-    return crc ^ 0xFFFFFFFF
+    return _CRC_TABLE
+
+
+def _crc_zero_tables():
+    """register' = M * register for one chunk of zero bytes; M is linear over GF(2), so it is tabulated per register byte"""
+    global _CRC_ZERO_TABLES
+    if _CRC_ZERO_TABLES is None:
+        tbl = _crc_table()
+        basis = (np.uint32(1) << np.arange(32, dtype=np.uint32)).astype(np.uint32)
+        for _ in range(_CRC_CHUNK):
+            basis = tbl[basis & 0xFF] ^ (basis >> np.uint32(8))
+        tables = np.zeros((4, 256), np.uint32)
+        for byte in range(4):
+            for v in range(256):
+                acc = np.uint32(0)
+                for bit in range(8):
+                    if v >> bit & 1:
+                        acc ^= basis[8 * byte + bit]
+                tables[byte, v] = acc
+        _CRC_ZERO_TABLES = tables
+    return _CRC_ZERO_TABLES
+
+
+def _crc_register(data, reg):
+    """raw crc32c register after feeding `data` (uint8 array), scalar table loop -- for short tails only"""
+    tbl = _crc_table()
+    reg = int(reg)
+    for b in data.tolist():
+        reg = int(tbl[(reg ^ b) & 0xFF]) ^ (reg >> 8)
+    return reg
+
+
+def crc32c(data):
+    """CRC-32C (Castagnoli) of a bytes-like object.  Tensors are hundreds of MB, so the byte recurrence runs vectorised over
+    4 KB chunks (numpy: all chunks advance one byte per step), and the chunk registers are chained with the linear
+    "append 4096 zero bytes" operator: R(A || B, x) = M_|B| R(A, x) xor R(B, 0)."""
+    buf = np.frombuffer(memoryview(data).cast("B"), dtype=np.uint8)
+    nfull = len(buf) // _CRC_CHUNK
+    reg = 0xFFFFFFFF
+    if nfull:
+        tbl = _crc_table()
+        chunks = buf[:nfull * _CRC_CHUNK].reshape(nfull, _CRC_CHUNK)
+        regs = np.zeros(nfull, np.uint32)
+        for j in range(_CRC_CHUNK):
+            regs = tbl[(regs ^ chunks[:, j]) & 0xFF] ^ (regs >> np.uint32(8))
+        z = _crc_zero_tables()
+        for c in regs.tolist():
+            reg = int(z[0, reg & 0xFF]) ^ int(z[1, (reg >> 8) & 0xFF]) ^ int(z[2, (reg >> 16) & 0xFF]) ^ int(z[3, reg >> 24]) ^ c
+    reg = _crc_register(buf[nfull * _CRC_CHUNK:], reg)
+    return reg ^ 0xFFFFFFFF
+
+
+def _crc32c(data):
+    return crc32c(data)
 
 
 def _build_block(items):
@@ -215,10 +271,12 @@ def _build_block(items):
     return bytes(body)
 
 
-def _entry_proto(dtype, shape, offset, size):
+def _entry_proto(dtype, shape, offset, size, crc):
+    """BundleEntryProto: dtype (1), shape (2), offset (4), size (5), crc32c (6, fixed32, masked) -- TensorFlow's BundleReader
+    rejects entries whose checksum is missing or wrong ("Checksum does not match")"""
     dims = b"".join(b"\x12" + _write_varint(len(d)) + d for d in (b"\x08" + _write_varint(s) for s in shape))
     return (b"\x08" + _write_varint(dtype) + b"\x12" + _write_varint(len(dims)) + dims +
-            b"\x20" + _write_varint(offset) + b"\x28" + _write_varint(size))
+            b"\x20" + _write_varint(offset) + b"\x28" + _write_varint(size) + b"\x35" + struct.pack("<I", _mask_crc(crc)))
 
 
 def save_tf_checkpoint(prefix, tensors, block_size=4096):
@@ -229,10 +287,11 @@ def save_tf_checkpoint(prefix, tensors, block_size=4096):
     offset = 0
     with open(prefix + ".data-00000-of-00001", "wb") as f:
         for name in names:
-            a = np.asarray(tensors[name], dtype="<f4")
-            f.write(a.tobytes(order="C"))
-            items.append((name.encode(), _entry_proto(_DT_FLOAT, a.shape, offset, a.nbytes)))
-            offset += a.nbytes
+            raw = np.asarray(tensors[name], dtype="<f4").tobytes(order="C")
+            f.write(raw)
+            a = np.asarray(tensors[name])
+            items.append((name.encode(), _entry_proto(_DT_FLOAT, a.shape, offset, len(raw), crc32c(raw))))
+            offset += len(raw)
     out = bytearray()
 
     def emit(block):

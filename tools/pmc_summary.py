@@ -27,6 +27,10 @@ def kernel_tag(name):
     if m:
         bm, wm, wn, tm, tn, taps = map(int, m.groups())
         return "conv_patch<%dx%d,t%d>" % (bm, wn * tn * (16 if bm == 16 else 32), taps)
+    m = re.search(r"conv_stream_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        nw, tm, tn, kw = map(int, m.groups())
+        return "conv_stream<%dx%d,w%dk%d>" % (32 * nw * tm, 32 * tn, nw, kw)
     m = re.search(r"deconv4_kernel<(\d+), (\d+), (\d+)", name)
     if m:
         bm, wm, wn = map(int, m.groups())
