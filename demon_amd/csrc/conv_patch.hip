@@ -181,11 +181,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
             }
     };
     // LOADS: global loads of step `next` into (lpreg, lareg); STORE: (spreg, sareg) hold step s+1 and go to the other buffer
-    auto kstep = [&](int buf, int next, float (&lpreg)[EPT], floatx4 (&lareg)[APER], const float (&spreg)[EPT],
+    // the loads walk through the K steps with two running pointers (no per-step index arithmetic in front of the MFMAs); a
+    // run-ahead past the end of the slice stays on the last step (re-read, never used)
+    const long pstride = (long)CKS * a.H * a.W, astride = (long)CKS * a.Mpad;
+    const float *__restrict__ pnext = nullptr;
+    const float *__restrict__ anext = nullptr;
+    int lnext = 0, llast = 0;
+    auto kstep = [&](int buf, float (&lpreg)[EPT], floatx4 (&lareg)[APER], const float (&spreg)[EPT],
                      const floatx4 (&sareg)[APER], unsigned sok, auto loads, auto store) {
         constexpr bool LOADS = decltype(loads)::value, STORE = decltype(store)::value;
-        const float *__restrict__ pbase = in0 + (long)next * CKS * a.H * a.W;
-        const float *__restrict__ abase = wp + (long)next * CKS * a.Mpad;
+        const float *__restrict__ pbase = pnext;
+        const float *__restrict__ abase = anext;
+        if (LOADS && lnext < llast) { pnext += pstride; anext += astride; ++lnext; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < G1; ++g) {
@@ -253,15 +260,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_patch_kernel(PatchArgs a)
     // during step s (buffer s&1): MFMAs on step s, loads of step s+2 into the set that step s freed, the set holding step s+1
     // goes to LDS buffer (s+1)&1.  Pairs of steps keep the set indices static.
     int s = 0;
+    if (nsteps > 0) {  // first step the loop loads: 2 (clamped to the last one)
+        lnext = phys(2);
+        llast = phys(nsteps - 1);
+        pnext = in0 + (long)lnext * pstride;
+        anext = wp + (long)lnext * astride;
+    }
     for (; s + 2 < nsteps; s += 2) {
-        kstep(0, phys(s + 2), pregA, aregA, pregB, aregB, okmask_of(phys(s + 1)), std::true_type{}, std::true_type{});
-        kstep(1, phys(s + 3), pregB, aregB, pregA, aregA, okmask_of(phys(s + 2)), std::true_type{}, std::true_type{});
+        kstep(0, pregA, aregA, pregB, aregB, okmask_of(phys(s + 1)), std::true_type{}, std::true_type{});
+        kstep(1, pregB, aregB, pregA, aregA, okmask_of(phys(s + 2)), std::true_type{}, std::true_type{});
     }
     if (s + 1 < nsteps) {
-        kstep(0, 0, pregA, aregA, pregB, aregB, okmask_of(phys(s + 1)), std::false_type{}, std::true_type{});
-        kstep(1, 0, pregA, aregA, pregA, aregA, 0u, std::false_type{}, std::false_type{});
+        kstep(0, pregA, aregA, pregB, aregB, okmask_of(phys(s + 1)), std::false_type{}, std::true_type{});
+        kstep(1, pregA, aregA, pregA, aregA, 0u, std::false_type{}, std::false_type{});
     } else if (nsteps > 0) {
-        kstep(0, 0, pregA, aregA, pregA, aregA, 0u, std::false_type{}, std::false_type{});
+        kstep(0, pregA, aregA, pregA, aregA, 0u, std::false_type{}, std::false_type{});
     }
     tl.mark(2);
 

@@ -350,7 +350,9 @@ void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
 // tile shape (G images x TH rows x TW cols) with the least staged input per output pixel, and split-K.
 struct PatchPlan { bool ok = false; int tile = 0, ntaps = 0; PatchArgs a; };
 
-bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile = -1)
+// only_tw >= 0 pins the pixel tile shape (index into the TW candidates below) instead of the cost model's choice: the autotuner
+// measures them (a plan stores it as ksplit + 1000 * (only_tw + 1))
+bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile = -1, int only_tw = -1)
 {
     static const int enabled = getenv("DEMON_CONV_PATCH") ? atoi(getenv("DEMON_CONV_PATCH")) : 1;
     pp.ok = false;
@@ -380,6 +382,7 @@ bool plan_patch(const Layer *L, int n, float *ws, PatchPlan &pp, int only_tile =
         const int tchunks = (L->Cin + tcks - 1) / tcks;
         if ((float)L->Cin / (tchunks * tcks) < 0.7f) continue;  // too much zero padding in K: the im2col kernel is better
         for (int tw_sel = 0; tw_sel < 4; ++tw_sel) {
+            if (only_tw >= 0 && tw_sel != only_tw) continue;
             int TW = tw_sel == 0 ? (Wp < bn ? Wp : bn) : (bn >> tw_sel);  // Wp/bn, bn/2, bn/4, bn/8
             if (TW < 8 || TW > Wp || TW > bn) continue;
             int TH = bn / TW;
@@ -606,8 +609,8 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 }
             } else if (kind == 1) {
                 PatchPlan pp;
-                if (tile >= 0 && tile < PTILE_COUNT && plan_patch(L, n, ws, pp, tile)) {
-                    if (ks > 0) pp.a.ksplit = ks < pp.a.nsteps_total ? ks : pp.a.nsteps_total;
+                if (tile >= 0 && tile < PTILE_COUNT && plan_patch(L, n, ws, pp, tile, ks / 1000 - 1)) {
+                    if (ks % 1000 > 0) pp.a.ksplit = ks % 1000 < pp.a.nsteps_total ? ks % 1000 : pp.a.nsteps_total;
                     launch_patch_plan(L, pp, a, P, ws, s);
                     return;
                 }
@@ -631,8 +634,9 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             }
             if (t.kind == 1) {
                 PatchPlan pp;
-                if (plan_patch(L, n, ws, pp, t.tile)) {
-                    if (t.ksplit > 0) pp.a.ksplit = t.ksplit < pp.a.nsteps_total ? t.ksplit : pp.a.nsteps_total;
+                const int tw = t.ksplit / 1000 - 1, ks = t.ksplit % 1000;
+                if (plan_patch(L, n, ws, pp, t.tile, tw)) {
+                    if (ks > 0) pp.a.ksplit = ks < pp.a.nsteps_total ? ks : pp.a.nsteps_total;
                     launch_patch_plan(L, pp, a, P, ws, s);
                     return;
                 }
@@ -685,7 +689,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
     for (int t = 0; t < PTILE_COUNT; ++t) {
         PatchPlan pp;
         if (!plan_patch(L, n, c->d_ws, pp, t)) continue;
-        cands.push_back({1, t, 0});  // 0 = the planner's own split-K
+        cands.push_back({1, t, 0});  // 0 = the planner's own pixel tile shape and split-K
         const long groups = (n + pp.a.G - 1) / pp.a.G;
         const long wgs = groups * pp.a.tiles_y * pp.a.tiles_x * patch_tile_mtiles(t, L->Cout, L->Mpad) * L->ncls;
         for (int ks : {1, 2, 3, 4, 6, 8}) {
@@ -693,6 +697,13 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
             if (ks > 1 && (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats) continue;
             if (wgs * ks < 96) continue;
             cands.push_back({1, t, ks});
+        }
+        // the other pixel tile shapes (TW = tile width candidates of plan_patch), planner's split-K
+        for (int tw = 0; tw < 4; ++tw) {
+            PatchPlan q;
+            if (!plan_patch(L, n, c->d_ws, q, t, tw)) continue;
+            if (q.a.TW == pp.a.TW && q.a.TH == pp.a.TH && q.a.G == pp.a.G) continue;  // the shape already measured
+            cands.push_back({1, t, 1000 * (tw + 1)});
         }
     }
     if (small_applies(L)) cands.push_back({3, 0, 0});
