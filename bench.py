@@ -181,8 +181,9 @@ def main():
     if not args.no_autotune:
         # per-layer kernel / tile / split-K selection (untimed set-up): the plan shipped in demon_amd/tuned/ for this
         # workload (measured once on an MI355X by tools/tune.py) or, when there is none, measured now
-        if not args.retune and ctx.load_tuned_plan(n):
-            plan_src = "demon_amd/tuned"
+        src_n = 0 if args.retune else ctx.load_tuned_plan(n)
+        if src_n:
+            plan_src = "demon_amd/tuned" if src_n == n else "demon_amd/tuned (plan of batch %d, nearest tuned size)" % src_n
         else:
             ctx.autotune(n)
             plan_src = "autotune at start-up"

@@ -30,6 +30,7 @@ _P = ctypes.c_void_p
 _I = ctypes.c_int
 _F = ctypes.c_float
 SIGNATURES = {
+    "demon_device_count": (_I, []),
     "demon_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "demon_create_v2": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "demon_create_ops": (_I, [ctypes.POINTER(_P), _I]),

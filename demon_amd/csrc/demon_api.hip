@@ -1468,6 +1468,12 @@ int demon_create_ops(demon_ctx **out, int device)
     return DEMON_OK;
 }
 
+int demon_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int demon_variant(const demon_ctx *c) { return c ? c->variant : 0; }
 
 int demon_destroy(demon_ctx *c)

@@ -84,8 +84,25 @@ def distribute_weights(ctx, host_weights, rank, world, route="rccl", comm=None):
     from . import weights as W
     if route == "rccl":
         own = comm is None
+        note = ""
         if own:
-            comm = NativeComm(rank, world, ctx.device)
+            # every rank must end up on the same route: agree on whether the communicator came up everywhere
+            try:
+                comm = NativeComm(rank, world, ctx.device)
+                ok = 1
+            except Exception as e:   # librccl missing, id exchange or ncclCommInitRank failed
+                comm, ok, note = None, 0, " (native RCCL init failed on rank %d: %s)" % (rank, e)
+            if world > 1:
+                import torch
+                import torch.distributed as dist
+                flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", ctx.device))
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                if comm is not None:
+                    comm.close()
+                dt, desc = distribute_weights(ctx, host_weights, rank, world, route="torch-gpu")
+                return dt, desc + " [fallback]" + note
         if rank == 0:
             ctx.set_weights(host_weights)      # TF layouts -> packed slab, on the root only
         t0 = time.perf_counter()

@@ -122,18 +122,29 @@ class DemonContext:
         for layer, (kind, tile, ks) in plan.items():
             self._check(self.lib.demon_plan_set(self.h, int(n), layer.encode(), int(kind), int(tile), int(ks)))
 
-    def load_tuned_plan(self, n, directory=None):
-        """installs demon_amd/tuned/plan_<H>x<W>_n<n>.json if it exists; returns True when a plan was loaded"""
+    def load_tuned_plan(self, n, directory=None, nearest=True):
+        """installs demon_amd/tuned/plan_<H>x<W>_n<n>.json; without a plan for exactly this batch the plan of the NEAREST tuned
+        batch size of the same shape (by ratio) is used -- its kernel families and tiles transfer, and kernels clamp a split-K
+        that does not fit -- instead of the untuned heuristics.  Returns the batch size of the plan installed (== n for an
+        exact hit), or 0 when none exists for this shape."""
+        import glob
         import json
         import os
+        import re
         directory = directory or os.environ.get("DEMON_PLAN_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned")
         tag = "" if self.version == 1 else "v2_"
-        path = os.path.join(directory, "plan_%s%dx%d_n%d.json" % (tag, self.H, self.W, int(n)))
-        if not os.path.exists(path):
-            return False
-        with open(path) as f:
+        stem = "plan_%s%dx%d_n" % (tag, self.H, self.W)
+        have = {}
+        for path in glob.glob(os.path.join(directory, stem + "*.json")):
+            m = re.match(re.escape(stem) + r"(\d+)\.json$", os.path.basename(path))
+            if m:
+                have[int(m.group(1))] = path
+        if not have or (int(n) not in have and not nearest):
+            return 0
+        src = int(n) if int(n) in have else min(have, key=lambda b: abs(np.log(b / float(n))))
+        with open(have[src]) as f:
             self.set_plan(n, json.load(f)["plan"])
-        return True
+        return src
 
     def set_option(self, key, value):
         self._check(self.lib.demon_set_option(self.h, key.encode(), int(value)))

@@ -53,6 +53,9 @@ typedef struct demon_outputs {
  * Replaces tf.InteractiveSession + the three network constructors
  * (examples/example.py:70-77; networks_original.py:23, :93, :204).  height/width must be multiples
  * of 32; 192x256 is the reference's fixed size (networks_original.py:38-42).                      */
+/* number of HIP devices visible to the library (0 when there is none or the runtime fails): replaces tf.test.is_gpu_available
+ * (examples/example.py:45) for callers that must not load a second GPU runtime just to ask */
+int demon_device_count(void);
 int demon_create(demon_ctx **ctx, int device, int max_batch, int height, int width);
 /* The retrained "v2" model: python/depthmotionnet/v2/networks.py:20-36, :80-122, :181-205 over v2/blocks.py (padding='same',
  * (24,32)/(48,64)/(96,128)/(192,256) separable pairs, 384 channels at level 5, dense5 bottleneck, motion_conv3..5b branch,

@@ -16,12 +16,9 @@ __version__ = "1.4.0-demon-amd-stub"
 class _Test:
     @staticmethod
     def is_gpu_available(cuda_only=False):
-        import ctypes
         try:
             from demon_amd import _lib
-            _lib.load()
-            import torch  # device query only
-            return bool(torch.cuda.is_available())
+            return _lib.load().demon_device_count() > 0   # asked through the library itself: no second GPU runtime is loaded
         except Exception:
             return False
 

@@ -287,10 +287,20 @@ def test_two_context_pipeline_matches_single_context(gpu_ctx, synth_weights):
         again = pipe.run(pair, img2_2, iterations=2)
     finally:
         pipe.close()
-    for i in range(3):
-        want = gpu_ctx.full(pair[4 * i:4 * i + 4], img2_2[4 * i:4 * i + 4], iterations=2)
-        for k in KEYS + ("predict_depth0", "predict_scale"):
-            np.testing.assert_array_equal(got[k][4 * i:4 * i + 4], want[k], err_msg=k)
+    from demon_amd import DemonContext
+    single = DemonContext(0, 4, 192, 256)     # same launch plan as the pipeline's contexts -> same summation order, same bits
+    try:
+        single.set_weights(synth_weights)
+        single.load_tuned_plan(4)
+        for i in range(3):
+            want = single.full(pair[4 * i:4 * i + 4], img2_2[4 * i:4 * i + 4], iterations=2)
+            for k in KEYS + ("predict_depth0", "predict_scale"):
+                np.testing.assert_array_equal(got[k][4 * i:4 * i + 4], want[k], err_msg=k)
+            other = gpu_ctx.full(pair[4 * i:4 * i + 4], img2_2[4 * i:4 * i + 4], iterations=2)   # heuristic plan: other order
+            for k in KEYS + ("predict_depth0",):
+                assert rel_l1(other[k], want[k]) < 1e-4, k
+    finally:
+        single.close()
     for k in got:
         np.testing.assert_array_equal(got[k], again[k])
 
@@ -375,3 +385,90 @@ def test_fused_input_assembly_is_exact(gpu_ctx):
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     finally:
         ctx.close()
+
+
+def test_reference_driver_statements_run_on_the_tensorflow_stub(tmp_path, synth_weights, gpu_ctx):
+    """The statements of the reference's examples/example.py:45-99 (GPU probe, session, the three nets built BEFORE the
+    checkpoint is restored, global_variables_initializer, Saver.restore, bootstrap + 3 x iterative + refinement) executed
+    against python/tf_stub + python/depthmotionnet in a fresh interpreter, on the sculpture pair prepared by the reference's own
+    prepare_input_data (golden arrays), weights from a TensorBundle checkpoint.  The unmodified reference file itself cannot be
+    run by a test (it is not in this repo, needs matplotlib and the real weights); this is its call sequence, line for line.
+    The result equals the device-resident pipeline of the C ABI on the same inputs, and two sessions keep their own weights."""
+    import subprocess
+    import sys
+    from demon_amd import tf_checkpoint as ck, weights
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    prefix = str(tmp_path / "weights" / "demon_original")
+    ck.save_tf_checkpoint(prefix, synth_weights)
+    other = weights.synthetic_weights(seed=9)
+    prefix2 = str(tmp_path / "weights2" / "demon_original")
+    ck.save_tf_checkpoint(prefix2, other)
+    out = str(tmp_path / "result.npz")
+    code = r'''
+import os, sys
+import numpy as np
+ROOT, PREFIX, PREFIX2, OUT = sys.argv[1:5]
+sys.path.insert(0, os.path.join(ROOT, "python", "tf_stub"))
+sys.path.insert(0, os.path.join(ROOT, "python"))
+sys.path.insert(0, ROOT)
+import tensorflow as tf
+from depthmotionnet.networks_original import *
+
+g = np.load(os.path.join(ROOT, "tests", "golden", "sculpture_inputs.npz"))
+if tf.test.is_gpu_available(True):
+    data_format = 'channels_first'
+else:
+    data_format = 'channels_last'
+input_data = {k: g["%s_%s_nearest" % (k, data_format)] if k == "image2_2" else None for k in ("image2_2",)}
+img1 = (g["image1_u8"].astype(np.float32) / 255 - 0.5)
+img2 = (g["image2_u8"].astype(np.float32) / 255 - 0.5)
+if data_format == 'channels_first':
+    img1, img2 = img1.transpose(2, 0, 1), img2.transpose(2, 0, 1)
+    input_data['image_pair'] = np.concatenate((img1, img2), axis=0)[np.newaxis]
+else:
+    input_data['image_pair'] = np.concatenate((img1, img2), axis=-1)[np.newaxis]
+input_data['image1'] = img1[np.newaxis]
+
+gpu_options = tf.GPUOptions()
+gpu_options.per_process_gpu_memory_fraction = 0.8
+session = tf.InteractiveSession(config=tf.ConfigProto(allow_soft_placement=True, gpu_options=gpu_options))
+bootstrap_net = BootstrapNet(session, data_format)
+iterative_net = IterativeNet(session, data_format)
+refine_net = RefinementNet(session, data_format)
+session.run(tf.global_variables_initializer())
+saver = tf.train.Saver()
+saver.restore(session, PREFIX)
+
+# a second session with other weights must not disturb the first one's nets
+session2 = tf.InteractiveSession()
+bootstrap2 = BootstrapNet(session2, data_format)
+tf.train.Saver().restore(session2, PREFIX2)
+
+result = bootstrap_net.eval(input_data['image_pair'], input_data['image2_2'])
+first = {k: v.copy() for k, v in result.items()}
+for i in range(3):
+    result = iterative_net.eval(input_data['image_pair'], input_data['image2_2'], result['predict_depth2'], result['predict_normal2'],
+                                result['predict_rotation'], result['predict_translation'])
+rotation = result['predict_rotation']
+translation = result['predict_translation']
+result = refine_net.eval(input_data['image1'], result['predict_depth2'])
+r2 = bootstrap2.eval(input_data['image_pair'], input_data['image2_2'])
+np.savez(OUT, depth0=result['predict_depth0'], rotation=rotation, translation=translation, boot_depth2=first['predict_depth2'],
+         other_depth2=r2['predict_depth2'], image_pair=input_data['image_pair'], image2_2=input_data['image2_2'])
+'''
+    r = subprocess.run([sys.executable, "-c", code, root, prefix, prefix2, out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = np.load(out)
+    from demon_amd import DemonContext
+    single = DemonContext(0, 1, 192, 256)      # as the nets of the driver: batch 1 with the shipped batch-1 launch plan
+    try:
+        single.set_weights(synth_weights)
+        single.load_tuned_plan(1)
+        want = single.full(res["image_pair"], res["image2_2"], iterations=3)
+    finally:
+        single.close()
+    np.testing.assert_array_equal(res["depth0"], want["predict_depth0"])
+    np.testing.assert_array_equal(res["rotation"], want["predict_rotation"])
+    np.testing.assert_array_equal(res["translation"], want["predict_translation"])
+    assert np.isfinite(res["depth0"]).all() and res["depth0"].shape == (1, 1, 192, 256)
+    assert not np.array_equal(res["other_depth2"], res["boot_depth2"])    # session2's nets ran on session2's weights

@@ -27,7 +27,8 @@ LAYERS = [
     ("rf conv2_1 128->128 3x3 @48x64", "conv", 128, 48, 64, 128, 3, 3, 1, 1),
     ("motion_fc1 6144->1024", "dense", 6144, 1, 1, 1024, 1, 1, 1, 1),
 ]
-VARIANTS = ["128x32", "128x64", "64x32", "64x64", "32x32", "32x64", "128x64w", "64x64w", "128x32w", "256x32w"]   # w: 64-row wave tiles
+VARIANTS = ["128x32", "128x64", "64x32", "64x64", "32x32", "32x64", "128x64w", "64x64w", "128x32w", "256x32w",   # w: 64-row wave tiles
+            "32x32k4", "32x32k8", "32x32k16", "32x64k8", "64x32wk8", "64x64wk4", "64x64wk8", "64x32k4"]                  # kN: N wave groups split K inside the workgroup
 
 
 def main():
@@ -51,7 +52,7 @@ def main():
                     best_old = (ms, tf, tile, ks)
         line = "%-32s old best %7.4f ms %6.1f TF (tile %d k%d)" % (lab, best_old[0], best_old[1], best_old[2], best_old[3])
         for v, name in enumerate(VARIANTS):
-            if mpad % int(name.split("x")[0].rstrip("w")):
+            if mpad % int(name.split("x")[0]):
                 continue
             best = None
             for ks in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48):
