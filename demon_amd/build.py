@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdemon_hip.so")
-SOURCES = ["demon_api.hip", "conv_mfma.hip", "conv_patch.hip", "conv_small.hip", "conv_pair.hip", "conv_stream.hip", "ops.hip"]
+SOURCES = ["demon_api.hip", "conv_mfma.hip", "conv_patch.hip", "conv_small.hip", "conv_pair.hip", "conv_stream.hip", "conv_frag.hip", "ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -69,7 +69,11 @@ def build(force=False, verbose=False, extra_flags=(), tag=""):
 
 
 if __name__ == "__main__":
-    if "--dbg" in sys.argv:
+    if "--sets4" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_STREAM_SETS=4"], tag="s4"))
+    elif "--sets2" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_STREAM_SETS=2"], tag="s2"))
+    elif "--dbg" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_STREAM_DBG"], tag="dbg"))
     elif "--timeline" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_TIMELINE"], tag="tl"))

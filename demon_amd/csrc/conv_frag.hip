@@ -1,0 +1,327 @@
+// conv_frag.hip -- LDS-tiled fp32-MFMA contraction on fragment-ordered weights, for the deep small-map layers.
+//
+// conv_stream.hip removed LDS and barriers from these layers and found the next limit: operand bytes through the vector
+// memory path (an ablation and a prefetch-depth sweep, DESIGN.md section 3.1: neither deeper prefetch nor removing the waits
+// helps; removing the loads does).  With every wave streaming its own A and B, a 64 x 32 wave tile moves 384 operand bytes per
+// MFMA.  Here the WM x WN waves of a workgroup share both operands through LDS, so a 128 x 64 tile moves 192 bytes per MFMA,
+// and the K loop keeps the pipeline of conv_patch.hip: one barrier per K-step, placed BETWEEN the two halves of the step's
+// MFMAs, fragments of the next half read behind the current one, global loads two steps ahead.
+//   A: the fragment-order copy of the weights (conv_stream.hip: Wf[cls][step][32-row block][lane][8]).  The workgroup's A tile of
+//      a K-step is ONE contiguous chunk of BM * 16 floats: copied with 16-byte loads, stored to LDS as [block][half][lane][4] so that
+//      a lane fetches the 4 + 4 values of its 8 MFMA groups with two conflict-free ds_read_b128;
+//   B: a thread owns one pixel of the tile and 16 * BN / NT reduction rows of the step: 4-byte loads from the NCHW activations (taps
+//      outside the image read the page of zeros), LDS [16][BN], fragments by ds_read_b32 (lane = pixel, half-wave = k parity).
+// Requirements as conv_stream.hip (Cin % 16 == 0).  Reduction order per output: tap major, channel minor == conv_mfma's order.
+#include <type_traits>
+
+#include "internal.h"
+
+namespace demon {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// WM x WN waves, a wave owns 32*TM channels x 32*TN pixels: BM = 32*TM*WM, BN = 32*TN*WN
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
+{
+    const ConvArgs &a = s.c;
+    TlScope tl(a.tl);
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int A4 = BM * 4;                  // float4 chunks of the A tile of one K-step
+    constexpr int APER = (A4 + NT - 1) / NT;
+    constexpr int BPER = 16 * BN / NT;          // reduction rows per thread
+    static_assert(A4 % NT == 0 && (16 * BN) % NT == 0 && NT % BN == 0, "bad tile");
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * 16];   // [buf][block][half][lane][4]
+    __shared__ __attribute__((aligned(16))) float Bs[2][16 * BN];   // [buf][k][pixel]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int cls = blockIdx.z / a.ksplit;
+    const int zs = blockIdx.z - cls * a.ksplit;
+    unsigned bx, by;
+    xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    const int m0 = by * BM;
+    const long p0 = (long)bx * BN;
+    const long P = (long)a.N * a.Hp * a.Wp;
+    const int HW = a.H * a.W;
+
+    // ---- B staging: this thread's pixel and its BPER rows of every K-step
+    const int bpx = tid % BN, brow0 = (tid / BN) * BPER;
+    const float *__restrict__ pb;
+    unsigned okbits = 0;
+    {
+        const long p = p0 + bpx;
+        const bool pv = p < P;
+        const long pc = pv ? p : 0;
+        const int x = (int)(pc % a.Wp);
+        const long t = pc / a.Wp;
+        const int y = (int)(t % a.Hp);
+        const int n = (int)(t / a.Hp);
+        const int iy0 = y * a.sy, ix0 = x * a.sx;
+        pb = a.in + (long)n * a.in_n_stride + (long)iy0 * a.W + ix0 + (long)brow0 * HW;
+        for (int t2 = 0; t2 < s.ntaps; ++t2) {
+            const bool ok = pv & ((unsigned)(iy0 + s.tapdy[cls][t2]) < (unsigned)a.H) & ((unsigned)(ix0 + s.tapdx[cls][t2]) < (unsigned)a.W);
+            okbits |= (ok ? 1u : 0u) << t2;
+        }
+    }
+    // ---- A staging: float4 chunk q = tid + i*NT of the contiguous tile; global chunk (block, lane, half) -> LDS (block, half, lane)
+    int alds[APER];
+#pragma unroll
+    for (int i = 0; i < APER; ++i) {
+        const int q = tid + i * NT;
+        const int blk = q >> 7, r = q & 127, ln = r >> 1, half = r & 1;
+        alds[i] = (blk * 128 + half * 64 + ln) * 4;
+    }
+
+    const int per_slice = (s.nsteps + a.ksplit - 1) / a.ksplit;
+    const int s_begin = zs * per_slice;
+    const int s_end = min(s.nsteps, s_begin + per_slice);
+    const int nsteps = s_end - s_begin;
+    const long a_step = (long)(a.Mpad >> 5) * 512;
+    const float *__restrict__ wf = s.wf + cls * s.cls_wf_stride + (long)s_begin * a_step + (long)(m0 >> 5) * 512 + tid * 4;
+
+    // loader position: step ls = (tap lt, channel block lc); cur = this thread's B address of channel row brow0 of that step
+    int ls = s_begin;
+    int lt = s_begin / s.csteps, lc = s_begin - lt * s.csteps;
+    const long cstride = (long)16 * HW;
+    const float *__restrict__ cur;
+    auto enter_tap = [&]() {
+        const int t2 = min(lt, s.ntaps - 1);
+        const int tdelta = s.tapdy[cls][t2] * a.W + s.tapdx[cls][t2];
+        cur = (((okbits >> t2) & 1u) ? pb + tdelta : s.zero + (long)brow0 * HW) + (long)lc * cstride;
+    };
+    enter_tap();
+
+    floatx4 areg[2][APER];
+    float breg[2][BPER];
+    auto load = [&](int set) {
+        if (ls < s_end) {  // (wave-uniform) a run-ahead past the end of the slice loads nothing
+#pragma unroll
+            for (int i = 0; i < APER; ++i) areg[set][i] = *reinterpret_cast<const floatx4 *>(wf + (long)i * NT * 4);
+#pragma unroll
+            for (int i = 0; i < BPER; ++i) breg[set][i] = cur[(long)i * HW];
+            wf += a_step;
+            cur += cstride;
+            ++ls;
+            if (++lc == s.csteps) { lc = 0; ++lt; enter_tap(); }
+        }
+    };
+    auto store_a_one = [&](int set, int i, int buf) { *reinterpret_cast<floatx4 *>(&As[buf][alds[i]]) = areg[set][i]; };
+    auto store_b_one = [&](int set, int i, int buf) { Bs[buf][(brow0 + i) * BN + bpx] = breg[set][i]; };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragments: ah[half][i] = the 4 A values of MFMA groups 4*half .. 4*half+3 of row block i; bv[kk][j]
+    floatx4 ah[2][TM];
+    float bv[8][TN];
+    auto read_a_half = [&](int buf, int half) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[half][i] = *reinterpret_cast<const floatx4 *>(&As[buf][(((wm * TM + i) * 2 + half) * 64 + lane) * 4]);
+    };
+    auto read_b_group = [&](int buf, int kk) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[buf][(2 * kk + lhi) * BN + (wn * TN + j) * 32 + l31];
+    };
+    auto mfma_group = [&](int kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[kk >> 2][i][kk & 3], bv[kk][j], acc[i][j], 0, 0, 0);
+    };
+    // one K-step on buffer `buf` (see conv_patch.hip for the buffer-safety argument of the mid-step barrier):
+    //   groups 0..3 | reads of groups 4..7 of this step | global loads of step s+2 into set `lset` | LDS writes of step s+1 from `sset`
+    //   barrier
+    //   groups 4..7 | reads of groups 0..3 of step s+1
+    auto kstep = [&](int buf, int lset, int sset, auto loads, auto store) {
+        constexpr bool LOADS = decltype(loads)::value, STORE = decltype(store)::value;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mfma_group(g);
+            if (g == 0) read_a_half(buf, 1);
+            read_b_group(buf, 4 + g);
+            if (LOADS && g == 1) load(lset);
+            if (STORE) {
+#pragma unroll
+                for (int i = g * APER / 4; i < (g + 1) * APER / 4; ++i) store_a_one(sset, i, buf ^ 1);
+#pragma unroll
+                for (int i = g * BPER / 4; i < (g + 1) * BPER / 4; ++i) store_b_one(sset, i, buf ^ 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (STORE) __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 4; g < 8; ++g) {
+            mfma_group(g);
+            if (STORE) {
+                if (g == 4) read_a_half(buf ^ 1, 0);
+                read_b_group(buf ^ 1, g - 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (nsteps > 0) {
+        load(0);                 // step 0
+        load(1);                 // step 1 (nothing when the slice has one step)
+#pragma unroll
+        for (int i = 0; i < APER; ++i) store_a_one(0, i, 0);
+#pragma unroll
+        for (int i = 0; i < BPER; ++i) store_b_one(0, i, 0);
+    }
+    __syncthreads();
+    tl.mark(1);
+    if (nsteps > 0) {
+        read_a_half(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) read_b_group(0, kk);
+    }
+    // step s on buffer s&1: loads of step s+2 into the set step s came from; the other set (step s+1) goes to the other buffer
+    int st = 0;
+    for (; st + 2 < nsteps; st += 2) {
+        kstep(0, 0, 1, std::true_type{}, std::true_type{});
+        kstep(1, 1, 0, std::true_type{}, std::true_type{});
+    }
+    if (st + 1 < nsteps) {
+        kstep(0, 0, 1, std::false_type{}, std::true_type{});
+        kstep(1, 0, 0, std::false_type{}, std::false_type{});
+    } else if (nsteps > 0) {
+        kstep(0, 0, 0, std::false_type{}, std::false_type{});
+    }
+    tl.mark(2);
+
+    // ---- epilogue (as conv_mfma.hip)
+    const int mw = m0 + wm * TM * 32;
+    const long pw = p0 + (long)wn * TN * 32;
+    if (a.ksplit > 1) {
+        float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long p = pw + j * 32 + l31;
+            if (p >= P) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = mw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    ws[(long)co * P + p] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+    const int pyc = cls >> 1, pxc = cls & 1;
+    const long plane = a.out_plane;
+    if (a.osx == 1 && a.osy == 1 && (a.Wp & 3) == 0 && (a.Cout & 3) == 0 && a.scale == nullptr) {
+        const int q = l31 >> 2, li = lane & 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const long p = pw + j * 32 + 4 * q;
+            const bool ok = p < P;
+            const long pc = ok ? p : 0;
+            const int x = (int)(pc % a.Wp);
+            const long t = pc / a.Wp;
+            const int y = (int)(t % a.Hp);
+            const int n = (int)(t / a.Hp);
+            float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)y * a.Wo + x;
+#pragma unroll
+            for (int irb = 0; irb < 4 * TM; ++irb) {
+                const int i = irb >> 2, rb = irb & 3;
+                float v0 = acc[i][j][4 * rb + 0], v1 = acc[i][j][4 * rb + 1], v2 = acc[i][j][4 * rb + 2], v3 = acc[i][j][4 * rb + 3];
+                {
+                    const bool odd = li & 1;
+                    float s0 = odd ? v0 : v1, s1 = odd ? v2 : v3;
+                    s0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, true));
+                    s1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, true));
+                    if (odd) { v0 = s0; v2 = s1; } else { v1 = s0; v3 = s1; }
+                }
+                {
+                    const bool hi = li & 2;
+                    float s0 = hi ? v0 : v2, s1 = hi ? v1 : v3;
+                    s0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s0), 0x4E, 0xF, 0xF, true));
+                    s1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s1), 0x4E, 0xF, 0xF, true));
+                    if (hi) { v0 = s0; v1 = s1; } else { v2 = s0; v3 = s1; }
+                }
+                const int co = mw + 32 * i + li + 8 * rb + 4 * lhi;
+                if (ok && co < a.Cout) {
+                    const float b = a.bias[co];
+                    floatx4 v = {v0 + b, v1 + b, v2 + b, v3 + b};
+                    if (a.act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.0f ? v[e] : 0.1f * v[e];
+                    }
+                    *reinterpret_cast<floatx4 *>(ob + (long)co * plane) = v;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const long p = pw + j * 32 + l31;
+        if (p >= P) continue;
+        const int x = (int)(p % a.Wp);
+        const long t = p / a.Wp;
+        const int y = (int)(t % a.Hp);
+        const int n = (int)(t / a.Hp);
+        float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)(y * a.osy + pyc) * a.Wo + (x * a.osx + pxc);
+        const float sc = a.scale ? a.scale[n] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (co < a.Cout) {
+                    float v = acc[i][j][r] + a.bias[co];
+                    if (a.act) v = v >= 0.0f ? v : 0.1f * v;
+                    if (co == 0) v *= sc;
+                    ob[(long)co * plane] = v;
+                }
+            }
+    }
+}
+
+struct FragVariant { int wm, wn, tm, tn; };
+static const FragVariant kFragVariants[FRAG_VARIANTS] = {{2, 2, 2, 1}, {2, 2, 1, 1}, {2, 2, 2, 2}, {2, 2, 1, 2}, {4, 1, 2, 1}, {1, 4, 2, 1}, {4, 1, 1, 1}, {1, 4, 2, 2}};
+
+int frag_variant_bm(int v) { return 32 * kFragVariants[v].tm * kFragVariants[v].wm; }
+int frag_variant_bn(int v) { return 32 * kFragVariants[v].tn * kFragVariants[v].wn; }
+
+template <int WM, int WN, int TM, int TN>
+static void launch_frag_variant(const StreamArgs &s, dim3 grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, stream, s);
+}
+
+void launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
+{
+    StreamArgs s = s_in;
+    s.c.ksplit = ksplit;
+    const ConvArgs &a = s.c;
+    const long P = (long)a.N * a.Hp * a.Wp;
+    const int bm = frag_variant_bm(variant), bn = frag_variant_bn(variant);
+    dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)(a.Mpad / bm), (unsigned)(nclasses * ksplit));
+    switch (variant) {
+        case 0: launch_frag_variant<2, 2, 2, 1>(s, grid, stream); break;
+        case 1: launch_frag_variant<2, 2, 1, 1>(s, grid, stream); break;
+        case 2: launch_frag_variant<2, 2, 2, 2>(s, grid, stream); break;
+        case 3: launch_frag_variant<2, 2, 1, 2>(s, grid, stream); break;
+        case 4: launch_frag_variant<4, 1, 2, 1>(s, grid, stream); break;
+        case 5: launch_frag_variant<1, 4, 2, 1>(s, grid, stream); break;
+        case 6: launch_frag_variant<4, 1, 1, 1>(s, grid, stream); break;
+        default: launch_frag_variant<1, 4, 2, 2>(s, grid, stream); break;
+    }
+    if (ksplit > 1) launch_splitk_reduce(s.c, nclasses, stream);
+}
+
+}  // namespace demon

@@ -185,38 +185,40 @@ __global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    StreamSet<TM, TN> f0, f1, f2;
-#ifdef DEMON_STREAM_DBG
-    for (int i = 0; i < TM; ++i) f0.a0[i] = f0.a1[i] = f1.a0[i] = f1.a1[i] = f2.a0[i] = f2.a1[i] = floatx4{1.0f, 0.5f, 0.25f, 2.0f};
-    for (int j = 0; j < TN; ++j)
-        for (int kk = 0; kk < 8; ++kk) f0.b[j][kk] = f1.b[j][kk] = f2.b[j][kk] = 0.001f * (lane + kk);
+#ifndef DEMON_STREAM_SETS
+#define DEMON_STREAM_SETS 3
 #endif
-    load(f0, std::true_type{});
-    load(f1, std::true_type{});
+    constexpr int NS = DEMON_STREAM_SETS;  // register sets: loads run NS - 1 K-steps ahead of the MFMAs
+    StreamSet<TM, TN> f[NS];
+#ifdef DEMON_STREAM_DBG
+    for (int q = 0; q < NS; ++q) {
+        for (int i = 0; i < TM; ++i) f[q].a0[i] = f[q].a1[i] = floatx4{1.0f, 0.5f, 0.25f, 2.0f};
+        for (int j = 0; j < TN; ++j)
+            for (int kk = 0; kk < 8; ++kk) f[q].b[j][kk] = 0.001f * (lane + kk);
+    }
+#endif
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q) load(f[q], std::true_type{});
     tl.mark(1);
-    int cs = s_begin;  // step being computed; f0 holds step cs, f1 step cs + 1
-    // steady state: every load of the iteration exists (steps cs+2 .. cs+4), so the loop body has no branches
-    while (cs + 5 <= s_end) {
-        load(f2, std::false_type{});
-        compute(f0);
-        load(f0, std::false_type{});
-        compute(f1);
-        load(f1, std::false_type{});
-        compute(f2);
-        cs += 3;
+    int cs = s_begin;  // step being computed; f[q] holds step cs + q
+    // steady state: every load of the iteration exists (steps cs+NS-1 .. cs+2NS-2), so the loop body has no branches
+    while (cs + 2 * NS - 1 <= s_end) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            load(f[(q + NS - 1) % NS], std::false_type{});
+            compute(f[q]);
+        }
+        cs += NS;
     }
     while (cs < s_end) {
-        load(f2, std::true_type{});
-        compute(f0);
-        if (cs + 1 < s_end) {
-            load(f0, std::true_type{});
-            compute(f1);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            if (cs + q < s_end) {
+                load(f[(q + NS - 1) % NS], std::true_type{});
+                compute(f[q]);
+            }
         }
-        if (cs + 2 < s_end) {
-            load(f1, std::true_type{});
-            compute(f2);
-        }
-        cs += 3;
+        cs += NS;
     }
     tl.mark(2);
 

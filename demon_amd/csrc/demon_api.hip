@@ -543,10 +543,9 @@ void refresh_stream_weights(const Layer *L, hipStream_t s)
     L->wf_dirty = false;
 }
 
-void run_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
+int fill_stream_args(const Layer *L, const ConvArgs &a, int ksplit, StreamArgs &sa, hipStream_t s)
 {
     refresh_stream_weights(L, s);
-    StreamArgs sa;
     sa.c = a;
     sa.wf = L->d_wf;
     sa.zero = L->zero;
@@ -574,10 +573,26 @@ void run_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipS
     }
     if (ksplit < 1) ksplit = 1;
     if (ksplit > sa.nsteps) ksplit = sa.nsteps;
+    return ksplit;
+}
+
+void run_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
+{
+    StreamArgs sa;
+    ksplit = fill_stream_args(L, a, ksplit, sa, s);
     launch_conv_stream(sa, variant, ksplit, L->ncls, s);
     // e.g. "conv_stream<256x32,w4k1>": tile, waves along Cout x K-splitting wave groups (rocprofv3: conv_stream_kernel<NW, TM, TN, KW>)
     snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_stream<%dx%d,w%dk%d>%s", stream_variant_bm(variant), stream_variant_bn(variant),
              stream_variant_waves(variant) / stream_variant_kw(variant), stream_variant_kw(variant), ksplit > 1 ? "+splitk" : "");
+    g_last_kernel = g_kernel_tag;
+}
+
+void run_frag(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
+{
+    StreamArgs sa;
+    ksplit = fill_stream_args(L, a, ksplit, sa, s);
+    launch_conv_frag(sa, variant, ksplit, L->ncls, s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_frag<%dx%d,v%d>%s", frag_variant_bm(variant), frag_variant_bn(variant), variant, ksplit > 1 ? "+splitk" : "");
     g_last_kernel = g_kernel_tag;
 }
 
@@ -607,6 +622,11 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                     run_stream(L, a, tile, clamp_split(ks), s);
                     return;
                 }
+            } else if (kind == 5) {
+                if (L->stream_ok() && tile >= 0 && tile < FRAG_VARIANTS && L->Mpad % frag_variant_bm(tile) == 0) {
+                    run_frag(L, a, tile, clamp_split(ks), s);
+                    return;
+                }
             } else if (kind == 1) {
                 PatchPlan pp;
                 if (tile >= 0 && tile < PTILE_COUNT && plan_patch(L, n, ws, pp, tile, ks / 1000 - 1)) {
@@ -632,6 +652,10 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 run_stream(L, a, t.tile, clamp_split(t.ksplit), s);
                 return;
             }
+            if (t.kind == 5 && L->stream_ok() && L->Mpad % frag_variant_bm(t.tile) == 0) {
+                run_frag(L, a, t.tile, clamp_split(t.ksplit), s);
+                return;
+            }
             if (t.kind == 1) {
                 PatchPlan pp;
                 const int tw = t.ksplit / 1000 - 1, ks = t.ksplit % 1000;
@@ -646,7 +670,10 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             }
         }
     }
-    if (L->force_tile >= 200) {  // demon_bench_layer: streaming kernel variant force_tile - 200
+    if (L->force_tile >= 300) {  // demon_bench_layer: fragment-tiled kernel variant force_tile - 300
+        const int v = L->force_tile - 300;
+        if (L->stream_ok() && v < FRAG_VARIANTS && L->Mpad % frag_variant_bm(v) == 0) { run_frag(L, a, v, clamp_split(L->force_split), s); return; }
+    } else if (L->force_tile >= 200) {  // demon_bench_layer: streaming kernel variant force_tile - 200
         const int v = L->force_tile - 200;
         if (L->stream_ok() && v < STREAM_VARIANTS && L->Mpad % stream_variant_bm(v) == 0) { run_stream(L, a, v, clamp_split(L->force_split), s); return; }
     }
@@ -719,6 +746,19 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
                 if (kw > 1 && (ks > 2 || nsteps < 2 * kw * ks)) continue;  // in-workgroup split-K is there to AVOID the reduce launch
                 if (waves * ks < (kw > 1 ? 128 : 512) || waves * ks > 16384) continue;  // enough waves to matter, at most 16 per SIMD
                 cands.push_back({4, v, ks});
+            }
+        }
+    }
+    if (L->stream_ok()) {
+        const int nsteps = L->K / 16;
+        for (int v = 0; v < FRAG_VARIANTS; ++v) {
+            if (L->Mpad % frag_variant_bm(v)) continue;
+            if (frag_variant_bn(v) > 32 && P * 2 <= frag_variant_bn(v)) continue;
+            const long wgs = (long)(L->Mpad / frag_variant_bm(v)) * ((P + frag_variant_bn(v) - 1) / frag_variant_bn(v)) * L->ncls;
+            for (int ks : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) {
+                if (ks > 1 && (ks > nsteps / 4 || (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
+                if (wgs * ks < 96 || wgs * ks > 4096) continue;
+                cands.push_back({5, v, ks});
             }
         }
     }
@@ -1708,16 +1748,18 @@ int demon_plan_get(const demon_ctx *c, int n, int layer_index, char *name, int n
 int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int tile, int ksplit)
 {
     if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
-    if (kind < 0 || kind > 4 || kind == 2 || tile < 0 || tile >= (kind == 1 ? (int)PTILE_COUNT : (kind == 4 ? (int)STREAM_VARIANTS : (int)TILE_COUNT)) || ksplit < 0)
+    if (kind < 0 || kind > 5 || kind == 2 || tile < 0 ||
+        tile >= (kind == 1 ? (int)PTILE_COUNT : (kind == 4 ? (int)STREAM_VARIANTS : (kind == 5 ? (int)FRAG_VARIANTS : (int)TILE_COUNT))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
             if (kind == 0 && L->Mpad % conv_tile_bm(tile)) return fail(c, DEMON_ERR_INVALID, "tile does not divide Cout");
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             if (kind == 4 && (!L->stream_ok() || L->Mpad % stream_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the streaming kernel does not apply to this layer");
+            if (kind == 5 && (!L->stream_ok() || L->Mpad % frag_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the fragment-tiled kernel does not apply to this layer");
             for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
             c->graphs.clear();
-            L->tuned[n] = Layer::Tuned{kind, tile, (kind == 0 || kind == 4) && ksplit < 1 ? 1 : ksplit};
+            L->tuned[n] = Layer::Tuned{kind, tile, (kind == 0 || kind == 4 || kind == 5) && ksplit < 1 ? 1 : ksplit};
             return DEMON_OK;
         }
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown layer ") + layer_name);
@@ -2102,7 +2144,7 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
 int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw,
                       int tile, int ksplit, int iters, float *avg_ms, double *flops)
 {
-    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || tile >= 200 + STREAM_VARIANTS) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || (tile >= 200 + STREAM_VARIANTS && tile < 300) || tile >= 300 + FRAG_VARIANTS) return fail(c, DEMON_ERR_INVALID, "bad argument");
     hipSetDevice(c->device);
     demon_ctx scratch;
     scratch.device = c->device;

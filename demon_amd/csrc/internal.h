@@ -141,6 +141,12 @@ int stream_variant_bn(int v);
 void launch_stream_repack(float *wf, const float *wp, int ncls, int K, int Mpad, long cls_w_stride, hipStream_t s);
 void launch_conv_stream(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
 
+// ---- LDS-tiled contraction on fragment-ordered weights (conv_frag.hip; same arguments as the streaming kernel) -----------------
+constexpr int FRAG_VARIANTS = 8;  // (waves along Cout, waves along pixels, row blocks per wave, column blocks per wave)
+int frag_variant_bm(int v);
+int frag_variant_bn(int v);
+void launch_conv_frag(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
+
 // ---- patch-staged convolution (conv_patch.hip) ---------------------------------------------------------
 constexpr int PATCH_EPT = 8;  // patch elements a thread stages per K-step
 struct PatchArgs {

@@ -31,6 +31,9 @@ VARIANTS = ["128x32", "128x64", "64x32", "64x64", "32x32", "32x64", "128x64w", "
             "32x32k4", "32x32k8", "32x32k16", "32x64k8", "64x32wk8", "64x64wk4", "64x64wk8", "64x32k4"]                  # kN: N wave groups split K inside the workgroup
 
 
+FRAG = ["128x64", "64x64", "128x128", "64x128", "256x32", "64x128b", "128x32", "64x256"]   # conv_frag.hip variants
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=32)
@@ -64,6 +67,19 @@ def main():
                     best = (ms, tf, ks)
             if best:
                 line += " | s%s k%d %6.4f %5.1f" % (name, best[2], best[0], best[1])
+        for v, name in enumerate(FRAG):
+            if mpad % int(name.split("x")[0]):
+                continue
+            best = None
+            for ks in (1, 2, 3, 4, 6, 8, 12, 16):
+                try:
+                    ms, tf = ctx.bench_layer(kind, args.n, cin, h, w, cout, kh, kw, sh, sw, tile=300 + v, ksplit=ks, iters=10)
+                except Exception:
+                    continue
+                if best is None or ms < best[0]:
+                    best = (ms, tf, ks)
+            if best:
+                line += " | f%s k%d %6.4f %5.1f" % (name, best[2], best[0], best[1])
         print(line, flush=True)
     ctx.close()
 
