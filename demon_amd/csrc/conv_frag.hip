@@ -21,8 +21,9 @@ namespace demon {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// WM x WN waves, a wave owns 32*TM channels x 32*TN pixels: BM = 32*TM*WM, BN = 32*TN*WN
-template <int WM, int WN, int TM, int TN>
+// WM x WN waves, a wave owns 32*TM channels x 32*TN pixels: BM = 32*TM*WM, BN = 32*TN*WN.  KS = K-steps (of 16 reduction
+// indices) per pipeline stage, i.e. per barrier: 2 for the small wave tiles, whose 8 MFMAs per step are too few between barriers.
+template <int WM, int WN, int TM, int TN, int KS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
 {
     const ConvArgs &a = s.c;
@@ -32,10 +33,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
     constexpr int A4 = BM * 4;                  // float4 chunks of the A tile of one K-step
     constexpr int APER = (A4 + NT - 1) / NT;
     constexpr int BPER = 16 * BN / NT;          // reduction rows per thread
-    static_assert(A4 % NT == 0 && (16 * BN) % NT == 0 && NT % BN == 0, "bad tile");
+    static_assert((A4 % NT == 0 || NT % A4 == 0) && (16 * BN) % NT == 0 && NT % BN == 0, "bad tile");
 
-    __shared__ __attribute__((aligned(16))) float As[2][BM * 16];   // [buf][block][half][lane][4]
-    __shared__ __attribute__((aligned(16))) float Bs[2][16 * BN];   // [buf][k][pixel]
+    constexpr int NG = 8 * KS, G1 = NG / 2;     // MFMA groups per stage / per half
+    __shared__ __attribute__((aligned(16))) float As[2][KS * BM * 16];   // [buf][sub-step][block][half][lane][4]
+    __shared__ __attribute__((aligned(16))) float Bs[2][KS * 16 * BN];   // [buf][k][pixel]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -69,10 +71,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
         }
     }
     // ---- A staging: float4 chunk q = tid + i*NT of the contiguous tile; global chunk (block, lane, half) -> LDS (block, half, lane)
+    const bool a_thread = A4 >= NT || tid < A4;   // BM = 32: the A tile has fewer 16-byte chunks than the workgroup has threads
     int alds[APER];
 #pragma unroll
     for (int i = 0; i < APER; ++i) {
-        const int q = tid + i * NT;
+        const int q = (tid + i * NT) % A4;
         const int blk = q >> 7, r = q & 127, ln = r >> 1, half = r & 1;
         alds[i] = (blk * 128 + half * 64 + ln) * 4;
     }
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
     const int s_end = min(s.nsteps, s_begin + per_slice);
     const int nsteps = s_end - s_begin;
     const long a_step = (long)(a.Mpad >> 5) * 512;
-    const float *__restrict__ wf = s.wf + cls * s.cls_wf_stride + (long)s_begin * a_step + (long)(m0 >> 5) * 512 + tid * 4;
+    const float *__restrict__ wf = s.wf + cls * s.cls_wf_stride + (long)s_begin * a_step + (long)(m0 >> 5) * 512 + (tid % A4) * 4;
 
     // loader position: step ls = (tap lt, channel block lc); cur = this thread's B address of channel row brow0 of that step
     int ls = s_begin;
@@ -96,22 +99,39 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
     };
     enter_tap();
 
-    floatx4 areg[2][APER];
-    float breg[2][BPER];
-    auto load = [&](int set) {
-        if (ls < s_end) {  // (wave-uniform) a run-ahead past the end of the slice loads nothing
+    floatx4 areg[2][KS][APER];
+    float breg[2][KS][BPER];
+    auto load = [&](int set) {   // one stage = KS K-steps; steps past the end of the slice become zeros (they multiply to nothing)
 #pragma unroll
-            for (int i = 0; i < APER; ++i) areg[set][i] = *reinterpret_cast<const floatx4 *>(wf + (long)i * NT * 4);
+        for (int u = 0; u < KS; ++u) {
+            if (ls < s_end) {  // (wave-uniform)
 #pragma unroll
-            for (int i = 0; i < BPER; ++i) breg[set][i] = cur[(long)i * HW];
-            wf += a_step;
-            cur += cstride;
-            ++ls;
-            if (++lc == s.csteps) { lc = 0; ++lt; enter_tap(); }
+                for (int i = 0; i < APER; ++i) areg[set][u][i] = *reinterpret_cast<const floatx4 *>(wf + (long)i * NT * 4);
+#pragma unroll
+                for (int i = 0; i < BPER; ++i) breg[set][u][i] = cur[(long)i * HW];
+                wf += a_step;
+                cur += cstride;
+                ++ls;
+                if (++lc == s.csteps) { lc = 0; ++lt; enter_tap(); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < APER; ++i) areg[set][u][i] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < BPER; ++i) breg[set][u][i] = 0.0f;
+            }
         }
     };
-    auto store_a_one = [&](int set, int i, int buf) { *reinterpret_cast<floatx4 *>(&As[buf][alds[i]]) = areg[set][i]; };
-    auto store_b_one = [&](int set, int i, int buf) { Bs[buf][(brow0 + i) * BN + bpx] = breg[set][i]; };
+    // piece q of a stage's LDS stores: q < KS*APER -> an A chunk, else a B element
+    auto store_piece = [&](int set, int q, int buf) {
+        if (q < KS * APER) {
+            const int u = q / APER, i = q - u * APER;
+            if (a_thread) *reinterpret_cast<floatx4 *>(&As[buf][u * (BM * 16) + alds[i]]) = areg[set][u][i];
+        } else {
+            const int r = q - KS * APER, u = r / BPER, i = r - u * BPER;
+            Bs[buf][(u * 16 + brow0 + i) * BN + bpx] = breg[set][u][i];
+        }
+    };
+    constexpr int NPIECE = KS * (APER + BPER);
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -121,83 +141,77 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // fragments: ah[half][i] = the 4 A values of MFMA groups 4*half .. 4*half+3 of row block i; bv[kk][j]
-    floatx4 ah[2][TM];
-    float bv[8][TN];
-    auto read_a_half = [&](int buf, int half) {
+    // fragments of one stage: group g = sub-step g / 8, k pair g % 8.  ah[q][i] = the 4 A values of groups 4q .. 4q+3 of row block i
+    floatx4 ah[2 * KS][TM];
+    float bv[NG][TN];
+    auto read_group = [&](int buf, int g) {   // the B values of group g, and with the first group of every four also their A values
+        if ((g & 3) == 0) {
+            const int u = g >> 3, half = (g >> 2) & 1;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) ah[half][i] = *reinterpret_cast<const floatx4 *>(&As[buf][(((wm * TM + i) * 2 + half) * 64 + lane) * 4]);
-    };
-    auto read_b_group = [&](int buf, int kk) {
+            for (int i = 0; i < TM; ++i)
+                ah[g >> 2][i] = *reinterpret_cast<const floatx4 *>(&As[buf][u * (BM * 16) + (((wm * TM + i) * 2 + half) * 64 + lane) * 4]);
+        }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[buf][(2 * kk + lhi) * BN + (wn * TN + j) * 32 + l31];
+        for (int j = 0; j < TN; ++j) bv[g][j] = Bs[buf][(2 * g + lhi) * BN + (wn * TN + j) * 32 + l31];
     };
-    auto mfma_group = [&](int kk) {
+    auto mfma_group = [&](int g) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[kk >> 2][i][kk & 3], bv[kk][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah[g >> 2][i][g & 3], bv[g][j], acc[i][j], 0, 0, 0);
     };
-    // one K-step on buffer `buf` (see conv_patch.hip for the buffer-safety argument of the mid-step barrier):
-    //   groups 0..3 | reads of groups 4..7 of this step | global loads of step s+2 into set `lset` | LDS writes of step s+1 from `sset`
+    // one stage on buffer `buf` (see conv_patch.hip for the buffer-safety argument of the mid-stage barrier):
+    //   groups [0,G1)  | reads of groups [G1,NG) of this stage | global loads of stage t+2 into set `lset` | LDS writes of stage t+1 from `sset`
     //   barrier
-    //   groups 4..7 | reads of groups 0..3 of step s+1
-    auto kstep = [&](int buf, int lset, int sset, auto loads, auto store) {
+    //   groups [G1,NG) | reads of groups [0,G1) of stage t+1
+    auto kstage = [&](int buf, int lset, int sset, auto loads, auto store) {
         constexpr bool LOADS = decltype(loads)::value, STORE = decltype(store)::value;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < G1; ++g) {
             mfma_group(g);
-            if (g == 0) read_a_half(buf, 1);
-            read_b_group(buf, 4 + g);
+            read_group(buf, G1 + g);
             if (LOADS && g == 1) load(lset);
             if (STORE) {
 #pragma unroll
-                for (int i = g * APER / 4; i < (g + 1) * APER / 4; ++i) store_a_one(sset, i, buf ^ 1);
-#pragma unroll
-                for (int i = g * BPER / 4; i < (g + 1) * BPER / 4; ++i) store_b_one(sset, i, buf ^ 1);
+                for (int q = g * NPIECE / G1; q < (g + 1) * NPIECE / G1; ++q) store_piece(sset, q, buf ^ 1);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (STORE) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 4; g < 8; ++g) {
+        for (int g = G1; g < NG; ++g) {
             mfma_group(g);
-            if (STORE) {
-                if (g == 4) read_a_half(buf ^ 1, 0);
-                read_b_group(buf ^ 1, g - 4);
-            }
+            if (STORE) read_group(buf ^ 1, g - G1);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    if (nsteps > 0) {
-        load(0);                 // step 0
-        load(1);                 // step 1 (nothing when the slice has one step)
+    const int nstages = (nsteps + KS - 1) / KS;
+    if (nstages > 0) {
+        load(0);                 // stage 0
+        load(1);                 // stage 1 (zeros when the slice has one stage)
 #pragma unroll
-        for (int i = 0; i < APER; ++i) store_a_one(0, i, 0);
-#pragma unroll
-        for (int i = 0; i < BPER; ++i) store_b_one(0, i, 0);
+        for (int q = 0; q < NPIECE; ++q) store_piece(0, q, 0);
     }
     __syncthreads();
     tl.mark(1);
-    if (nsteps > 0) {
-        read_a_half(0, 0);
+    if (nstages > 0) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) read_b_group(0, kk);
+        for (int g = 0; g < G1; ++g) read_group(0, g);
     }
-    // step s on buffer s&1: loads of step s+2 into the set step s came from; the other set (step s+1) goes to the other buffer
+    // stage t on buffer t&1: loads of stage t+2 into the set stage t came from; the other set (stage t+1) goes to the other buffer
     int st = 0;
-    for (; st + 2 < nsteps; st += 2) {
-        kstep(0, 0, 1, std::true_type{}, std::true_type{});
-        kstep(1, 1, 0, std::true_type{}, std::true_type{});
+    for (; st + 2 < nstages; st += 2) {
+        kstage(0, 0, 1, std::true_type{}, std::true_type{});
+        kstage(1, 1, 0, std::true_type{}, std::true_type{});
     }
-    if (st + 1 < nsteps) {
-        kstep(0, 0, 1, std::false_type{}, std::true_type{});
-        kstep(1, 0, 0, std::false_type{}, std::false_type{});
-    } else if (nsteps > 0) {
-        kstep(0, 0, 0, std::false_type{}, std::false_type{});
+    if (st + 1 < nstages) {
+        kstage(0, 0, 1, std::false_type{}, std::true_type{});
+        kstage(1, 0, 0, std::false_type{}, std::false_type{});
+    } else if (nstages > 0) {
+        kstage(0, 0, 0, std::false_type{}, std::false_type{});
     }
     tl.mark(2);
 
@@ -291,16 +305,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
     }
 }
 
-struct FragVariant { int wm, wn, tm, tn; };
-static const FragVariant kFragVariants[FRAG_VARIANTS] = {{2, 2, 2, 1}, {2, 2, 1, 1}, {2, 2, 2, 2}, {2, 2, 1, 2}, {4, 1, 2, 1}, {1, 4, 2, 1}, {4, 1, 1, 1}, {1, 4, 2, 2}};
+struct FragVariant { int wm, wn, tm, tn, ks; };
+static const FragVariant kFragVariants[FRAG_VARIANTS] = {{2, 2, 2, 1, 1}, {2, 2, 1, 1, 1}, {2, 2, 2, 2, 1}, {2, 2, 1, 2, 1}, {4, 1, 2, 1, 1}, {1, 4, 2, 1, 1},
+                                                         {4, 1, 1, 1, 1}, {1, 4, 2, 2, 1}, {2, 2, 1, 1, 2}, {4, 1, 1, 1, 2}, {2, 2, 2, 1, 2}, {1, 4, 2, 1, 2},
+                                                         {2, 2, 1, 2, 2}, {1, 4, 1, 1, 2}};
 
 int frag_variant_bm(int v) { return 32 * kFragVariants[v].tm * kFragVariants[v].wm; }
 int frag_variant_bn(int v) { return 32 * kFragVariants[v].tn * kFragVariants[v].wn; }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int KS>
 static void launch_frag_variant(const StreamArgs &s, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, stream, s);
+    hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN, KS>), grid, dim3(64 * WM * WN), 0, stream, s);
 }
 
 void launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
@@ -312,14 +328,20 @@ void launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclas
     const int bm = frag_variant_bm(variant), bn = frag_variant_bn(variant);
     dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)(a.Mpad / bm), (unsigned)(nclasses * ksplit));
     switch (variant) {
-        case 0: launch_frag_variant<2, 2, 2, 1>(s, grid, stream); break;
-        case 1: launch_frag_variant<2, 2, 1, 1>(s, grid, stream); break;
-        case 2: launch_frag_variant<2, 2, 2, 2>(s, grid, stream); break;
-        case 3: launch_frag_variant<2, 2, 1, 2>(s, grid, stream); break;
-        case 4: launch_frag_variant<4, 1, 2, 1>(s, grid, stream); break;
-        case 5: launch_frag_variant<1, 4, 2, 1>(s, grid, stream); break;
-        case 6: launch_frag_variant<4, 1, 1, 1>(s, grid, stream); break;
-        default: launch_frag_variant<1, 4, 2, 2>(s, grid, stream); break;
+        case 0: launch_frag_variant<2, 2, 2, 1, 1>(s, grid, stream); break;
+        case 1: launch_frag_variant<2, 2, 1, 1, 1>(s, grid, stream); break;
+        case 2: launch_frag_variant<2, 2, 2, 2, 1>(s, grid, stream); break;
+        case 3: launch_frag_variant<2, 2, 1, 2, 1>(s, grid, stream); break;
+        case 4: launch_frag_variant<4, 1, 2, 1, 1>(s, grid, stream); break;
+        case 5: launch_frag_variant<1, 4, 2, 1, 1>(s, grid, stream); break;
+        case 6: launch_frag_variant<4, 1, 1, 1, 1>(s, grid, stream); break;
+        case 7: launch_frag_variant<1, 4, 2, 2, 1>(s, grid, stream); break;
+        case 8: launch_frag_variant<2, 2, 1, 1, 2>(s, grid, stream); break;
+        case 9: launch_frag_variant<4, 1, 1, 1, 2>(s, grid, stream); break;
+        case 10: launch_frag_variant<2, 2, 2, 1, 2>(s, grid, stream); break;
+        case 11: launch_frag_variant<1, 4, 2, 1, 2>(s, grid, stream); break;
+        case 12: launch_frag_variant<2, 2, 1, 2, 2>(s, grid, stream); break;
+        default: launch_frag_variant<1, 4, 1, 1, 2>(s, grid, stream); break;
     }
     if (ksplit > 1) launch_splitk_reduce(s.c, nclasses, stream);
 }

@@ -51,7 +51,7 @@ def test_all_variants_agree(gpu_ctx, layer):
     want = _ref(kind, x, w, b, (sh, sw))
     plans = [(3, 0, 0)] + [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(9) for ks in (0, 2, 3, 5)]
     plans += [(4, v, ks) for v in range(18) for ks in (1, 2, 3, 5)]   # register-streaming kernel (applies when Cin % 16 == 0)
-    plans += [(5, v, ks) for v in range(8) for ks in (1, 2, 3, 5)]    # fragment-tiled kernel (same requirement)
+    plans += [(5, v, ks) for v in range(14) for ks in (1, 2, 3, 5)]    # fragment-tiled kernel (same requirement)
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
@@ -75,7 +75,7 @@ def test_streaming_kernel_is_bit_identical_to_im2col_and_runs_dense(gpu_ctx):
         for v in range(10):   # variants without in-workgroup split-K keep the im2col summation order
             os.environ["DEMON_FORCE_PLAN"] = "4,%d,1" % v
             np.testing.assert_array_equal(gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True), ref)
-        for v in range(8):    # ... and so does the fragment-tiled kernel
+        for v in range(14):   # ... and so does the fragment-tiled kernel
             os.environ["DEMON_FORCE_PLAN"] = "5,%d,1" % v
             np.testing.assert_array_equal(gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True), ref)
         xd = rng.standard_normal((7, 6144)).astype(np.float32)

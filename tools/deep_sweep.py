@@ -31,7 +31,8 @@ VARIANTS = ["128x32", "128x64", "64x32", "64x64", "32x32", "32x64", "128x64w", "
             "32x32k4", "32x32k8", "32x32k16", "32x64k8", "64x32wk8", "64x64wk4", "64x64wk8", "64x32k4"]                  # kN: N wave groups split K inside the workgroup
 
 
-FRAG = ["128x64", "64x64", "128x128", "64x128", "256x32", "64x128b", "128x32", "64x256"]   # conv_frag.hip variants
+FRAG = ["128x64", "64x64", "128x128", "64x128", "256x32", "64x128b", "128x32", "64x256",   # conv_frag.hip variants
+        "64x64s2", "128x32s2", "128x64s2", "64x128bs2", "64x128s2", "32x128s2"]              # s2: two K-steps per barrier
 
 
 def main():
