@@ -23,12 +23,15 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 // WM x WN waves, a wave owns 32*TM channels x 32*TN pixels: BM = 32*TM*WM, BN = 32*TN*WN.  KS = K-steps (of 16 reduction
 // indices) per pipeline stage, i.e. per barrier: 2 for the small wave tiles, whose 8 MFMAs per step are too few between barriers.
-template <int WM, int WN, int TM, int TN, int KS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
+// KW > 1: KW groups of WM x WN waves share the output tile and split its K range (each with its own LDS buffers, all meeting at the
+// same barriers); their accumulators are summed through LDS in group order at the end -- split-K without partial sums in HBM and
+// without a reduce launch, for the layers whose tiles are too few to fill the chip.
+template <int WM, int WN, int TM, int TN, int KS, int KW>
+__global__ __launch_bounds__(64 * WM * WN * KW) void conv_frag_kernel(StreamArgs s)
 {
     const ConvArgs &a = s.c;
     TlScope tl(a.tl);
-    constexpr int NT = 64 * WM * WN;
+    constexpr int NT = 64 * WM * WN;   // threads of one wave group
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int A4 = BM * 4;                  // float4 chunks of the A tile of one K-step
     constexpr int APER = (A4 + NT - 1) / NT;
@@ -36,10 +39,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
     static_assert((A4 % NT == 0 || NT % A4 == 0) && (16 * BN) % NT == 0 && NT % BN == 0, "bad tile");
 
     constexpr int NG = 8 * KS, G1 = NG / 2;     // MFMA groups per stage / per half
-    __shared__ __attribute__((aligned(16))) float As[2][KS * BM * 16];   // [buf][sub-step][block][half][lane][4]
-    __shared__ __attribute__((aligned(16))) float Bs[2][KS * 16 * BN];   // [buf][k][pixel]
+    constexpr int ASZ = KS * BM * 16, BSZ = KS * 16 * BN;   // floats of one A / B buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int gk = threadIdx.x / NT;                        // K-splitting group of this thread
+    float *const Asg = smem + gk * (2 * (ASZ + BSZ));       // [buf][sub-step][block][half][lane][4]
+    float *const Bsg = Asg + 2 * ASZ;                       // [buf][k][pixel]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x - gk * NT, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int cls = blockIdx.z / a.ksplit;
@@ -81,9 +87,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
     }
 
     const int per_slice = (s.nsteps + a.ksplit - 1) / a.ksplit;
-    const int s_begin = zs * per_slice;
-    const int s_end = min(s.nsteps, s_begin + per_slice);
-    const int nsteps = s_end - s_begin;
+    int s_begin = zs * per_slice;
+    int s_end = min(s.nsteps, s_begin + per_slice);
+    int nsteps = max(s_end - s_begin, 0);
+    if (KW > 1) {  // this group's share; every group runs the same number of stages (missing steps load zeros) to meet the same barriers
+        const int per_group = (nsteps + KW - 1) / KW;
+        s_begin += gk * per_group;
+        s_end = min(s_end, s_begin + per_group);
+        nsteps = per_group;
+    }
     const long a_step = (long)(a.Mpad >> 5) * 512;
     const float *__restrict__ wf = s.wf + cls * s.cls_wf_stride + (long)s_begin * a_step + (long)(m0 >> 5) * 512 + (tid % A4) * 4;
 
@@ -125,10 +137,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
     auto store_piece = [&](int set, int q, int buf) {
         if (q < KS * APER) {
             const int u = q / APER, i = q - u * APER;
-            if (a_thread) *reinterpret_cast<floatx4 *>(&As[buf][u * (BM * 16) + alds[i]]) = areg[set][u][i];
+            if (a_thread) *reinterpret_cast<floatx4 *>(&Asg[buf * ASZ + u * (BM * 16) + alds[i]]) = areg[set][u][i];
         } else {
             const int r = q - KS * APER, u = r / BPER, i = r - u * BPER;
-            Bs[buf][(u * 16 + brow0 + i) * BN + bpx] = breg[set][u][i];
+            Bsg[buf * BSZ + (u * 16 + brow0 + i) * BN + bpx] = breg[set][u][i];
         }
     };
     constexpr int NPIECE = KS * (APER + BPER);
@@ -149,10 +161,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
             const int u = g >> 3, half = (g >> 2) & 1;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                ah[g >> 2][i] = *reinterpret_cast<const floatx4 *>(&As[buf][u * (BM * 16) + (((wm * TM + i) * 2 + half) * 64 + lane) * 4]);
+                ah[g >> 2][i] = *reinterpret_cast<const floatx4 *>(&Asg[buf * ASZ + u * (BM * 16) + (((wm * TM + i) * 2 + half) * 64 + lane) * 4]);
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[g][j] = Bs[buf][(2 * g + lhi) * BN + (wn * TN + j) * 32 + l31];
+        for (int j = 0; j < TN; ++j) bv[g][j] = Bsg[buf * BSZ + (2 * g + lhi) * BN + (wn * TN + j) * 32 + l31];
     };
     auto mfma_group = [&](int g) {
 #pragma unroll
@@ -214,6 +226,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
         kstage(0, 0, 0, std::false_type{}, std::false_type{});
     }
     tl.mark(2);
+
+    if constexpr (KW > 1) {
+        // sum the KW partial tiles through LDS (the tile buffers are free now): every group parks its accumulators, group g adds
+        // up the registers r = g, g + KW, ... of all groups in group order, group 0 collects the sums and runs the epilogue alone
+        constexpr int R = TM * TN * 16;
+        __syncthreads();
+        float *base = smem + (long)wave * (R * 64) + lane;
+        float *mine = base + (long)gk * (WM * WN * R * 64);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+        __syncthreads();
+        for (int r = gk; r < R; r += KW) {
+            float sum = base[r * 64];
+            for (int g = 1; g < KW; ++g) sum += base[(long)g * (WM * WN * R * 64) + r * 64];
+            base[r * 64] = sum;
+        }
+        __syncthreads();
+        if (gk != 0) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = base[((i * TN + j) * 16 + r) * 64];
+    }
 
     // ---- epilogue (as conv_mfma.hip)
     const int mw = m0 + wm * TM * 32;
@@ -305,18 +346,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_frag_kernel(StreamArgs s)
     }
 }
 
-struct FragVariant { int wm, wn, tm, tn, ks; };
-static const FragVariant kFragVariants[FRAG_VARIANTS] = {{2, 2, 2, 1, 1}, {2, 2, 1, 1, 1}, {2, 2, 2, 2, 1}, {2, 2, 1, 2, 1}, {4, 1, 2, 1, 1}, {1, 4, 2, 1, 1},
-                                                         {4, 1, 1, 1, 1}, {1, 4, 2, 2, 1}, {2, 2, 1, 1, 2}, {4, 1, 1, 1, 2}, {2, 2, 2, 1, 2}, {1, 4, 2, 1, 2},
-                                                         {2, 2, 1, 2, 2}, {1, 4, 1, 1, 2}};
+struct FragVariant { int wm, wn, tm, tn, ks, kw; };
+static const FragVariant kFragVariants[FRAG_VARIANTS] = {
+    {2, 2, 2, 1, 1, 1}, {2, 2, 1, 1, 1, 1}, {2, 2, 2, 2, 1, 1}, {2, 2, 1, 2, 1, 1}, {4, 1, 2, 1, 1, 1}, {1, 4, 2, 1, 1, 1}, {4, 1, 1, 1, 1, 1},
+    {1, 4, 2, 2, 1, 1}, {2, 2, 1, 1, 2, 1}, {4, 1, 1, 1, 2, 1}, {2, 2, 2, 1, 2, 1}, {1, 4, 2, 1, 2, 1}, {2, 2, 1, 2, 2, 1}, {1, 4, 1, 1, 2, 1},
+    {4, 1, 1, 1, 1, 2}, {4, 1, 1, 1, 1, 4}, {2, 2, 1, 1, 1, 2}, {2, 2, 1, 1, 1, 4}, {2, 2, 2, 1, 1, 2}, {2, 2, 2, 1, 1, 4}, {1, 4, 2, 1, 1, 2}, {4, 1, 2, 1, 1, 2}};
 
 int frag_variant_bm(int v) { return 32 * kFragVariants[v].tm * kFragVariants[v].wm; }
 int frag_variant_bn(int v) { return 32 * kFragVariants[v].tn * kFragVariants[v].wn; }
+int frag_variant_kw(int v) { return kFragVariants[v].kw; }
 
-template <int WM, int WN, int TM, int TN, int KS>
+template <int WM, int WN, int TM, int TN, int KS, int KW>
 static void launch_frag_variant(const StreamArgs &s, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN, KS>), grid, dim3(64 * WM * WN), 0, stream, s);
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr size_t tiles = sizeof(float) * KW * 2 * (KS * BM * 16 + KS * 16 * BN);
+    constexpr size_t red = KW > 1 ? sizeof(float) * KW * WM * WN * TM * TN * 16 * 64 : 0;
+    constexpr size_t lds = tiles > red ? tiles : red;
+    static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
+    if (lds > 48 * 1024) {  // more dynamic LDS than the default limit: opt in once per instantiation
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_kernel<WM, WN, TM, TN, KS, KW>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)once;
+    }
+    hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN, KS, KW>), grid, dim3(64 * WM * WN * KW), lds, stream, s);
 }
 
 void launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
@@ -328,20 +381,28 @@ void launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclas
     const int bm = frag_variant_bm(variant), bn = frag_variant_bn(variant);
     dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)(a.Mpad / bm), (unsigned)(nclasses * ksplit));
     switch (variant) {
-        case 0: launch_frag_variant<2, 2, 2, 1, 1>(s, grid, stream); break;
-        case 1: launch_frag_variant<2, 2, 1, 1, 1>(s, grid, stream); break;
-        case 2: launch_frag_variant<2, 2, 2, 2, 1>(s, grid, stream); break;
-        case 3: launch_frag_variant<2, 2, 1, 2, 1>(s, grid, stream); break;
-        case 4: launch_frag_variant<4, 1, 2, 1, 1>(s, grid, stream); break;
-        case 5: launch_frag_variant<1, 4, 2, 1, 1>(s, grid, stream); break;
-        case 6: launch_frag_variant<4, 1, 1, 1, 1>(s, grid, stream); break;
-        case 7: launch_frag_variant<1, 4, 2, 2, 1>(s, grid, stream); break;
-        case 8: launch_frag_variant<2, 2, 1, 1, 2>(s, grid, stream); break;
-        case 9: launch_frag_variant<4, 1, 1, 1, 2>(s, grid, stream); break;
-        case 10: launch_frag_variant<2, 2, 2, 1, 2>(s, grid, stream); break;
-        case 11: launch_frag_variant<1, 4, 2, 1, 2>(s, grid, stream); break;
-        case 12: launch_frag_variant<2, 2, 1, 2, 2>(s, grid, stream); break;
-        default: launch_frag_variant<1, 4, 1, 1, 2>(s, grid, stream); break;
+        case 0: launch_frag_variant<2, 2, 2, 1, 1, 1>(s, grid, stream); break;
+        case 1: launch_frag_variant<2, 2, 1, 1, 1, 1>(s, grid, stream); break;
+        case 2: launch_frag_variant<2, 2, 2, 2, 1, 1>(s, grid, stream); break;
+        case 3: launch_frag_variant<2, 2, 1, 2, 1, 1>(s, grid, stream); break;
+        case 4: launch_frag_variant<4, 1, 2, 1, 1, 1>(s, grid, stream); break;
+        case 5: launch_frag_variant<1, 4, 2, 1, 1, 1>(s, grid, stream); break;
+        case 6: launch_frag_variant<4, 1, 1, 1, 1, 1>(s, grid, stream); break;
+        case 7: launch_frag_variant<1, 4, 2, 2, 1, 1>(s, grid, stream); break;
+        case 8: launch_frag_variant<2, 2, 1, 1, 2, 1>(s, grid, stream); break;
+        case 9: launch_frag_variant<4, 1, 1, 1, 2, 1>(s, grid, stream); break;
+        case 10: launch_frag_variant<2, 2, 2, 1, 2, 1>(s, grid, stream); break;
+        case 11: launch_frag_variant<1, 4, 2, 1, 2, 1>(s, grid, stream); break;
+        case 12: launch_frag_variant<2, 2, 1, 2, 2, 1>(s, grid, stream); break;
+        case 13: launch_frag_variant<1, 4, 1, 1, 2, 1>(s, grid, stream); break;
+        case 14: launch_frag_variant<4, 1, 1, 1, 1, 2>(s, grid, stream); break;
+        case 15: launch_frag_variant<4, 1, 1, 1, 1, 4>(s, grid, stream); break;
+        case 16: launch_frag_variant<2, 2, 1, 1, 1, 2>(s, grid, stream); break;
+        case 17: launch_frag_variant<2, 2, 1, 1, 1, 4>(s, grid, stream); break;
+        case 18: launch_frag_variant<2, 2, 2, 1, 1, 2>(s, grid, stream); break;
+        case 19: launch_frag_variant<2, 2, 2, 1, 1, 4>(s, grid, stream); break;
+        case 20: launch_frag_variant<1, 4, 2, 1, 1, 2>(s, grid, stream); break;
+        default: launch_frag_variant<4, 1, 2, 1, 1, 2>(s, grid, stream); break;
     }
     if (ksplit > 1) launch_splitk_reduce(s.c, nclasses, stream);
 }

@@ -755,9 +755,11 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
             if (L->Mpad % frag_variant_bm(v)) continue;
             if (frag_variant_bn(v) > 32 && P * 2 <= frag_variant_bn(v)) continue;
             const long wgs = (long)(L->Mpad / frag_variant_bm(v)) * ((P + frag_variant_bn(v) - 1) / frag_variant_bn(v)) * L->ncls;
+            const int kw = frag_variant_kw(v);
             for (int ks : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) {
                 if (ks > 1 && (ks > nsteps / 4 || (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
-                if (wgs * ks < 96 || wgs * ks > 4096) continue;
+                if (kw > 1 && (ks > 2 || nsteps < 4 * kw * ks)) continue;  // in-workgroup split-K is there to avoid the reduce launch
+                if (wgs * ks * kw < 96 || wgs * ks > 4096) continue;
                 cands.push_back({5, v, ks});
             }
         }

@@ -142,9 +142,10 @@ void launch_stream_repack(float *wf, const float *wp, int ncls, int K, int Mpad,
 void launch_conv_stream(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
 
 // ---- LDS-tiled contraction on fragment-ordered weights (conv_frag.hip; same arguments as the streaming kernel) -----------------
-constexpr int FRAG_VARIANTS = 14;  // (waves along Cout, waves along pixels, row blocks per wave, column blocks per wave)
+constexpr int FRAG_VARIANTS = 22;  // (waves along Cout, waves along pixels, row blocks per wave, column blocks per wave)
 int frag_variant_bm(int v);
 int frag_variant_bn(int v);
+int frag_variant_kw(int v);  // K-splitting wave groups inside a workgroup (1: none)
 void launch_conv_frag(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
 
 // ---- patch-staged convolution (conv_patch.hip) ---------------------------------------------------------

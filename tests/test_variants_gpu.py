@@ -51,7 +51,7 @@ def test_all_variants_agree(gpu_ctx, layer):
     want = _ref(kind, x, w, b, (sh, sw))
     plans = [(3, 0, 0)] + [(0, t, ks) for t in range(8) for ks in (1, 2, 3, 5)] + [(1, t, ks) for t in range(9) for ks in (0, 2, 3, 5)]
     plans += [(4, v, ks) for v in range(18) for ks in (1, 2, 3, 5)]   # register-streaming kernel (applies when Cin % 16 == 0)
-    plans += [(5, v, ks) for v in range(14) for ks in (1, 2, 3, 5)]    # fragment-tiled kernel (same requirement)
+    plans += [(5, v, ks) for v in range(22) for ks in (1, 2, 3, 5)]    # fragment-tiled kernel (same requirement)
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
