@@ -90,22 +90,7 @@ def cpu_baseline(weights, budget_s=30.0):
                       % (legs[1]["runs"], legs[8]["runs"], cores, nproc, best)}
 
 
-def rocprof_kernel_name(tag):
-    """profile tag -> how rocprofv3 --kernel-trace names the kernel (profiles/*_kernel_stats.csv)"""
-    base = tag.split("+")[0]
-    fam, _, rest = base.partition("<")
-    dims = rest.rstrip(">").split(",")[0].split("x") if rest else []
-    if fam == "conv_mfma" and len(dims) == 2:
-        return "demon::conv_mfma_kernel<%s, %s, ...>" % tuple(dims)
-    if fam == "conv_patch" and len(dims) == 2:
-        return "demon::conv_patch_kernel<%s, ...> (%sx%s tile, %s taps)" % (dims[0], dims[0], dims[1], rest.rstrip(">").split(",t")[-1])
-    if fam == "deconv4":
-        return "demon::deconv4_kernel<%s, ...>" % dims[0]
-    if fam == "conv_stream" and len(dims) == 2:
-        w, k = rest.rstrip(">").split(",")[1].lstrip("w").split("k")
-        tm = int(dims[0]) // (32 * int(w))
-        return "demon::conv_stream_kernel<%s, %d, %d, %s> (%sx%s tile)" % (w, tm, int(dims[1]) // 32, k, dims[0], dims[1])
-    return "demon::%s_kernel" % fam
+from demon_amd.kernel_names import rocprof_kernel_name  # noqa: E402
 
 
 def main():
@@ -268,7 +253,7 @@ def main():
             }
             fam_achieved = flops / (ms * 1e-3) / 1e12
             result["roofline_family"] = {
-                "kernel": "all conv / deconv / dense launches (conv_mfma, conv_patch, deconv4, conv_pair, conv_small kernels)",
+                "kernel": "all conv / deconv / dense launches (conv_frag, conv_stream, conv_patch, deconv4, conv_pair, conv_mfma, conv_small kernels)",
                 "bound": "mfma", "achieved": fam_achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": fam_achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                 "algorithmic_bytes_per_launch": sum(r["bytes"] for r in conv) / len(conv),

@@ -1,0 +1,72 @@
+"""Two names for one kernel instance: the tag demon_profile_full() reports (e.g. `conv_frag<128x32,v6>+splitk`) and the
+demangled template name rocprofv3 --kernel-trace prints.  bench.py and tools/pmc_summary.py join their tables on these."""
+import functools
+import os
+import re
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+
+
+@functools.lru_cache(None)
+def frag_variants():
+    """variant index -> (WM, WN, TM, TN, KS, KW), read from the dispatch switch in csrc/conv_frag.hip"""
+    src = open(os.path.join(CSRC, "conv_frag.hip")).read()
+    table = {}
+    for m in re.finditer(r"case (\d+): launch_frag_variant<([\d, ]+)>", src):
+        table[int(m.group(1))] = tuple(int(x) for x in m.group(2).split(","))
+    m = re.search(r"default: launch_frag_variant<([\d, ]+)>", src)
+    if m:
+        table[max(table) + 1] = tuple(int(x) for x in m.group(1).split(","))
+    return table
+
+
+def kernel_tag(name):
+    """rocprofv3 kernel name -> profile tag of the same template instance (without the +splitk suffix)"""
+    m = re.search(r"conv_mfma_kernel<(\d+), (\d+)", name)
+    if m:
+        return "conv_mfma<%sx%s>" % m.groups()
+    m = re.search(r"conv_patch_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        bm, wm, wn, tm, tn, taps = map(int, m.groups())
+        return "conv_patch<%dx%d,t%d>" % (bm, wn * tn * (16 if bm == 16 else 32), taps)
+    m = re.search(r"conv_stream_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        nw, tm, tn, kw = map(int, m.groups())
+        return "conv_stream<%dx%d,w%dk%d>" % (32 * nw * tm, 32 * tn, nw, kw)
+    m = re.search(r"conv_frag_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        params = tuple(map(int, m.groups()))
+        wm, wn, tm, tn, ks, kw = params
+        for v, p in sorted(frag_variants().items()):
+            if p == params:
+                return "conv_frag<%dx%d,v%d>" % (32 * tm * wm, 32 * tn * wn, v)
+        return "conv_frag<%dx%d,?>" % (32 * tm * wm, 32 * tn * wn)
+    m = re.search(r"deconv4_kernel<(\d+), (\d+), (\d+)", name)
+    if m:
+        bm, wm, wn = map(int, m.groups())
+        return "deconv4<%dx%d>" % (bm, wn * 32)
+    m = re.search(r"demon::(\w+?)_kernel", name)
+    return m.group(1) if m else name.split("(")[0]
+
+
+def rocprof_kernel_name(tag):
+    """profile tag -> how rocprofv3 --kernel-trace names the kernel (profiles/*_kernel_stats.csv)"""
+    base = tag.split("+")[0]
+    fam, _, rest = base.partition("<")
+    dims = rest.rstrip(">").split(",")[0].split("x") if rest else []
+    if fam == "conv_mfma" and len(dims) == 2:
+        return "demon::conv_mfma_kernel<%s, %s, ...>" % tuple(dims)
+    if fam == "conv_patch" and len(dims) == 2:
+        return "demon::conv_patch_kernel<%s, ...> (%sx%s tile, %s taps)" % (dims[0], dims[0], dims[1], rest.rstrip(">").split(",t")[-1])
+    if fam == "deconv4":
+        return "demon::deconv4_kernel<%s, ...>" % dims[0]
+    if fam == "conv_stream" and len(dims) == 2:
+        w, k = rest.rstrip(">").split(",")[1].lstrip("w").split("k")
+        tm = int(dims[0]) // (32 * int(w))
+        return "demon::conv_stream_kernel<%s, %d, %d, %s> (%sx%s tile)" % (w, tm, int(dims[1]) // 32, k, dims[0], dims[1])
+    if fam == "conv_frag" and len(dims) == 2:
+        v = rest.rstrip(">").split(",v")[-1]
+        p = frag_variants().get(int(v)) if v.isdigit() else None
+        if p:
+            return "demon::conv_frag_kernel<%d, %d, %d, %d, %d, %d> (%sx%s tile)" % (p + (dims[0], dims[1]))
+    return "demon::%s_kernel" % fam

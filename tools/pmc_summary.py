@@ -16,27 +16,7 @@ import re
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-
-
-def kernel_tag(name):
-    """rocprofv3 kernel name -> the tag demon_profile_full / bench.py use for the same template instance"""
-    m = re.search(r"conv_mfma_kernel<(\d+), (\d+)", name)
-    if m:
-        return "conv_mfma<%sx%s>" % m.groups()
-    m = re.search(r"conv_patch_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
-    if m:
-        bm, wm, wn, tm, tn, taps = map(int, m.groups())
-        return "conv_patch<%dx%d,t%d>" % (bm, wn * tn * (16 if bm == 16 else 32), taps)
-    m = re.search(r"conv_stream_kernel<(\d+), (\d+), (\d+), (\d+)", name)
-    if m:
-        nw, tm, tn, kw = map(int, m.groups())
-        return "conv_stream<%dx%d,w%dk%d>" % (32 * nw * tm, 32 * tn, nw, kw)
-    m = re.search(r"deconv4_kernel<(\d+), (\d+), (\d+)", name)
-    if m:
-        bm, wm, wn = map(int, m.groups())
-        return "deconv4<%dx%d>" % (bm, wn * 32)
-    m = re.search(r"demon::(\w+?)_kernel", name)
-    return m.group(1) if m else name.split("(")[0]
+from demon_amd.kernel_names import kernel_tag  # noqa: E402
 
 
 def load(d):
@@ -49,7 +29,7 @@ def load(d):
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
-            fam = "conv" if any(k in name for k in ("conv_mfma_kernel", "conv_patch_kernel", "deconv4_kernel", "conv_pair_kernel")) else name.split("(")[0].replace("demon::", "")
+            fam = "conv" if any(k in name for k in ("conv_mfma_kernel", "conv_patch_kernel", "deconv4_kernel", "conv_pair_kernel", "conv_stream_kernel", "conv_frag_kernel")) else name.split("(")[0].replace("demon::", "")
             agg[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg["kernel:" + kernel_tag(name)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
