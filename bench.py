@@ -258,6 +258,7 @@ def main():
                 "frac": fam_achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                 "algorithmic_bytes_per_launch": sum(r["bytes"] for r in conv) / len(conv),
                 "launches": len(conv), "splitk_reduce_launches": sum(1 for r in conv if "+splitk" in r["kernel"]),
+                "splitk_combined_in_launch": sum(1 for r in conv if "+fixup" in r["kernel"]),
                 "avg_launch_ms": ms / len(conv), "flops_per_launch": flops / len(conv),
                 "gflop_per_pair_launched": flops / n / 1e9, "kernel_time_share": ms / total_ms,
             }

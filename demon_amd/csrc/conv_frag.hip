@@ -260,20 +260,24 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void conv_frag_kernel(StreamArgs
     const int mw = m0 + wm * TM * 32;
     const long pw = p0 + (long)wn * TN * 32;
     if (a.ksplit > 1) {
-        float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
+        if (a.tickets) {  // combined inside this launch (internal.h)
+            if (!splitk_combine_in_launch<TM, TN>(acc, a.ws, a.tickets, a.ksplit, cls, zs, WM * WN, wave)) return;
+        } else {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
+            float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const long p = pw + j * 32 + l31;
-            if (p >= P) continue;
+            for (int j = 0; j < TN; ++j) {
+                const long p = pw + j * 32 + l31;
+                if (p >= P) continue;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = mw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    ws[(long)co * P + p] = acc[i][j][r];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = mw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        ws[(long)co * P + p] = acc[i][j][r];
+                    }
+            }
+            return;
         }
-        return;
     }
     const int pyc = cls >> 1, pxc = cls & 1;
     const long plane = a.out_plane;
@@ -372,7 +376,7 @@ static void launch_frag_variant(const StreamArgs &s, dim3 grid, hipStream_t stre
     hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN, KS, KW>), grid, dim3(64 * WM * WN * KW), lds, stream, s);
 }
 
-void launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
+bool launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
 {
     StreamArgs s = s_in;
     s.c.ksplit = ksplit;
@@ -380,6 +384,10 @@ void launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclas
     const long P = (long)a.N * a.Hp * a.Wp;
     const int bm = frag_variant_bm(variant), bn = frag_variant_bn(variant);
     dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)(a.Mpad / bm), (unsigned)(nclasses * ksplit));
+    const FragVariant &fv = kFragVariants[variant];
+    if (ksplit <= 1 || (long)grid.x * grid.y * nclasses * fv.wm * fv.wn > kSplitKTickets ||
+        splitk_slab_floats((long)grid.x * grid.y, fv.wm * fv.wn, fv.tm, fv.tn, nclasses, ksplit) > kSplitKWorkspaceFloats)
+        s.c.tickets = nullptr;
     switch (variant) {
         case 0: launch_frag_variant<2, 2, 2, 1, 1, 1>(s, grid, stream); break;
         case 1: launch_frag_variant<2, 2, 1, 1, 1, 1>(s, grid, stream); break;
@@ -404,7 +412,8 @@ void launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclas
         case 20: launch_frag_variant<1, 4, 2, 1, 1, 2>(s, grid, stream); break;
         default: launch_frag_variant<4, 1, 2, 1, 1, 2>(s, grid, stream); break;
     }
-    if (ksplit > 1) launch_splitk_reduce(s.c, nclasses, stream);
+    if (ksplit > 1 && !s.c.tickets) launch_splitk_reduce(s.c, nclasses, stream);
+    return s.c.tickets != nullptr;
 }
 
 }  // namespace demon

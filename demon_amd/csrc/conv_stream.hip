@@ -254,20 +254,24 @@ __global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
 
     // ---- epilogue (as conv_mfma.hip)
     if (a.ksplit > 1) {
-        float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
+        if (a.tickets) {  // combined inside this launch (internal.h)
+            if (!splitk_combine_in_launch<TM, TN>(acc, a.ws, a.tickets, a.ksplit, cls, zs, NW, wave)) return;
+        } else {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
+            float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const long p = p0 + j * 32 + l31;
-            if (p >= P) continue;
+            for (int j = 0; j < TN; ++j) {
+                const long p = p0 + j * 32 + l31;
+                if (p >= P) continue;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                    ws[(long)co * P + p] = acc[i][j][r];
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                        ws[(long)co * P + p] = acc[i][j][r];
+                    }
+            }
+            return;
         }
-        return;
     }
     const int pyc = cls >> 1, pxc = cls & 1;
     const long plane = a.out_plane;
@@ -359,7 +363,7 @@ static void launch_stream_variant(const StreamArgs &s, dim3 grid, hipStream_t st
     hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW>), grid, dim3(64 * NW * KW), lds, stream, s);
 }
 
-void launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
+bool launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
 {
     StreamArgs s = s_in;
     s.c.ksplit = ksplit;
@@ -367,6 +371,10 @@ void launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int ncl
     const long P = (long)a.N * a.Hp * a.Wp;
     const int bm = stream_variant_bm(variant), bn = stream_variant_bn(variant);
     dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)(a.Mpad / bm), (unsigned)(nclasses * ksplit));
+    const StreamVariant &sv = kStreamVariants[variant];
+    if (ksplit <= 1 || (long)grid.x * grid.y * nclasses * sv.nw > kSplitKTickets ||
+        splitk_slab_floats((long)grid.x * grid.y, sv.nw, sv.tm, sv.tn, nclasses, ksplit) > kSplitKWorkspaceFloats)
+        s.c.tickets = nullptr;
     switch (variant) {
         case 0: launch_stream_variant<4, 1, 1, 1>(s, grid, stream); break;
         case 1: launch_stream_variant<4, 1, 2, 1>(s, grid, stream); break;
@@ -387,7 +395,8 @@ void launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int ncl
         case 16: launch_stream_variant<1, 2, 2, 8>(s, grid, stream); break;
         default: launch_stream_variant<2, 1, 1, 4>(s, grid, stream); break;
     }
-    if (ksplit > 1) launch_splitk_reduce(s.c, nclasses, stream);
+    if (ksplit > 1 && !s.c.tickets) launch_splitk_reduce(s.c, nclasses, stream);
+    return s.c.tickets != nullptr;
 }
 
 }  // namespace demon

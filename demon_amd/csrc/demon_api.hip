@@ -33,7 +33,9 @@ thread_local std::string g_create_error;
 // with "+splitk" when a split-K reduce launch follows); demon_profile_full reads it to attribute time per kernel
 unsigned long long *g_timeline_dev = nullptr;  // diagnostic build (demon_debug_timeline): where the kernels write their records
 thread_local const char *g_last_kernel = nullptr;
-thread_local char g_kernel_tag[32];
+thread_local char g_kernel_tag[48];
+// suffix of a kernel tag: "+splitk" = a conv_splitk_reduce launch follows, "+fixup" = K slices combined inside the launch
+const char *split_suffix(int ksplit, bool in_launch) { return ksplit > 1 ? (in_launch ? "+fixup" : "+splitk") : ""; }
 void set_kernel_tag(const char *family, int bm, int bn, int taps, bool splitk)
 {
     // e.g. "conv_mfma<128x32>+splitk" (rocprofv3: conv_mfma_kernel<128, 32, ...>), "conv_patch<64x128,t5>", "deconv4<32x128>"
@@ -154,6 +156,10 @@ float *dev_alloc(demon_ctx *c, size_t bytes)
     c->allocations.push_back(p);
     return (float *)p;
 }
+
+// split-K workspace: kSplitKWorkspaceFloats of partial sums followed by kSplitKTickets arrival counters (zero whenever no
+// launch is in flight: the last arriver of a tile puts its counter back, internal.h)
+float *alloc_splitk_workspace(demon_ctx *c);
 
 // named activation buffer, sized for max_batch; same name -> same memory (the five sub-nets run one
 // after the other on one stream and share their encoder/decoder buffers)
@@ -311,7 +317,13 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
     return DEMON_OK;
 }
 
-constexpr long kSplitKWorkspaceFloats = 16l << 20;  // 64 MiB
+
+float *alloc_splitk_workspace(demon_ctx *c)
+{
+    float *ws = dev_alloc(c, sizeof(float) * kSplitKWorkspaceFloats + sizeof(unsigned) * kSplitKTickets);
+    if (ws && hipMemset(ws + kSplitKWorkspaceFloats, 0, sizeof(unsigned) * kSplitKTickets) != hipSuccess) return nullptr;
+    return ws;
+}
 
 void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
 {
@@ -336,6 +348,7 @@ void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
     a.act = L->act;
     a.cls_w_stride = (long)L->Krows * L->Mpad;
     a.ksplit = 1;
+    a.tickets = nullptr;
     a.tl = g_timeline_dev;
     static const int xcd_order = getenv("DEMON_XCD_ORDER") ? atoi(getenv("DEMON_XCD_ORDER")) : 1;
     a.xcd = xcd_order;
@@ -576,30 +589,46 @@ int fill_stream_args(const Layer *L, const ConvArgs &a, int ksplit, StreamArgs &
     return ksplit;
 }
 
+// Plans of the kinds 0 / 4 / 5 store "combine the K slices inside the launch" (tickets, internal.h) as ksplit + 1000.
+unsigned *split_tickets(const ConvArgs &a, int &ksplit)
+{
+    const bool in_launch = ksplit >= 1000;
+    ksplit %= 1000;
+    return in_launch && a.ws ? reinterpret_cast<unsigned *>(a.ws + kSplitKWorkspaceFloats) : nullptr;
+}
+
 void run_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
 {
     StreamArgs sa;
+    unsigned *tickets = split_tickets(a, ksplit);
     ksplit = fill_stream_args(L, a, ksplit, sa, s);
-    launch_conv_stream(sa, variant, ksplit, L->ncls, s);
+    sa.c.tickets = ksplit > 1 ? tickets : nullptr;
+    const bool in_launch = launch_conv_stream(sa, variant, ksplit, L->ncls, s);
     // e.g. "conv_stream<256x32,w4k1>": tile, waves along Cout x K-splitting wave groups (rocprofv3: conv_stream_kernel<NW, TM, TN, KW>)
     snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_stream<%dx%d,w%dk%d>%s", stream_variant_bm(variant), stream_variant_bn(variant),
-             stream_variant_waves(variant) / stream_variant_kw(variant), stream_variant_kw(variant), ksplit > 1 ? "+splitk" : "");
+             stream_variant_waves(variant) / stream_variant_kw(variant), stream_variant_kw(variant), split_suffix(ksplit, in_launch));
     g_last_kernel = g_kernel_tag;
 }
 
 void run_frag(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
 {
     StreamArgs sa;
+    unsigned *tickets = split_tickets(a, ksplit);
     ksplit = fill_stream_args(L, a, ksplit, sa, s);
-    launch_conv_frag(sa, variant, ksplit, L->ncls, s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_frag<%dx%d,v%d>%s", frag_variant_bm(variant), frag_variant_bn(variant), variant, ksplit > 1 ? "+splitk" : "");
+    sa.c.tickets = ksplit > 1 ? tickets : nullptr;
+    const bool in_launch = launch_conv_frag(sa, variant, ksplit, L->ncls, s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_frag<%dx%d,v%d>%s", frag_variant_bm(variant), frag_variant_bn(variant), variant, split_suffix(ksplit, in_launch));
     g_last_kernel = g_kernel_tag;
 }
 
-void run_mfma(const ConvArgs &a, ConvPlan plan, int ncls, hipStream_t s)
+void run_mfma(const ConvArgs &a_in, ConvPlan plan, int ncls, hipStream_t s)
 {
-    launch_conv_mfma(a, plan, ncls, s);
-    set_kernel_tag("conv_mfma", conv_tile_bm(plan.tile), conv_tile_bn(plan.tile), 0, plan.ksplit > 1);
+    ConvArgs a = a_in;
+    a.tickets = split_tickets(a, plan.ksplit);
+    if (plan.ksplit <= 1) a.tickets = nullptr;
+    const bool in_launch = launch_conv_mfma(a, plan, ncls, s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_mfma<%dx%d>%s", conv_tile_bm(plan.tile), conv_tile_bn(plan.tile), split_suffix(plan.ksplit, in_launch));
+    g_last_kernel = g_kernel_tag;
 }
 
 void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
@@ -608,8 +637,10 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
     fill_conv_args(L, n, ws, a);
     const long P = (long)n * a.Hp * a.Wp;
     auto clamp_split = [&](int k) {
+        const int in_launch = k >= 1000 ? 1000 : 0;  // see split_tickets
+        k %= 1000;
         while (k > 1 && (!ws || (long)L->ncls * k * L->Mpad * P > kSplitKWorkspaceFloats)) --k;
-        return k;
+        return k > 1 ? k + in_launch : k;
     };
     // test hook: DEMON_FORCE_PLAN="kind,tile,ksplit" forces one kernel variant for every layer it applies to
     if (const char *fp = getenv("DEMON_FORCE_PLAN")) {
@@ -635,7 +666,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                     return;
                 }
             } else if (tile >= 0 && tile < TILE_COUNT && L->Mpad % conv_tile_bm(tile) == 0) {
-                run_mfma(a, ConvPlan{tile, clamp_split(ks < 1 ? 1 : (ks > L->Kpad / 16 ? L->Kpad / 16 : ks))}, L->ncls, s);
+                run_mfma(a, ConvPlan{tile, clamp_split(ks < 1 ? 1 : (ks % 1000 > L->Kpad / 16 ? L->Kpad / 16 + ks / 1000 * 1000 : ks))}, L->ncls, s);
                 return;
             }
         }
@@ -768,7 +799,8 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;
     float best = 1e30f;
     Layer::Tuned best_t{0, heur.tile, heur.ksplit};
-    for (const Cand &cd : cands) {
+    bool failed = false;
+    auto measure = [&](const Cand &cd) -> float {
         L->tuned[n] = Layer::Tuned{cd.kind, cd.tile, cd.ksplit};
         // timed as a replayed hipGraph of five launches, like the real sequences run: the host-side planning of an eager
         // launch (tens of microseconds for the small layers) must not leak into the comparison
@@ -788,11 +820,27 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
         }
         if (exec) hipGraphExecDestroy(exec);
         if (graph) hipGraphDestroy(graph);
-        if (!ok) { hipEventDestroy(e0); hipEventDestroy(e1); return DEMON_ERR_HIP; }
+        if (!ok) { failed = true; return 1e30f; }
         float ms = 0;
         hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) { best = ms; best_t = Layer::Tuned{cd.kind, cd.tile, cd.ksplit}; }
+        return ms;
+    };
+    // split-K candidates of the im2col / streaming / fragment-tiled kernels exist twice: with the reduce launch and with the K
+    // slices combined inside the launch (ksplit + 1000).  The second form is measured for the fastest few of the first.
+    std::vector<std::pair<float, size_t>> split_ms;
+    for (size_t i = 0; i < cands.size() && !failed; ++i) {
+        const float ms = measure(cands[i]);
+        if ((cands[i].kind == 0 || cands[i].kind == 4 || cands[i].kind == 5) && cands[i].ksplit > 1) split_ms.push_back({ms, i});
     }
+    std::sort(split_ms.begin(), split_ms.end());
+    for (size_t q = 0; q < split_ms.size() && q < 6 && !failed; ++q) {
+        Cand cd = cands[split_ms[q].second];
+        cd.ksplit += 1000;
+        cands.push_back(cd);
+        measure(cd);
+    }
+    if (failed) { hipEventDestroy(e0); hipEventDestroy(e1); return DEMON_ERR_HIP; }
     if (const char *pk = getenv("DEMON_TUNE_PICK")) {  // test hook: deterministic choice = candidate index
         const Cand &cd = cands[(size_t)atoi(pk) % cands.size()];
         best_t = Layer::Tuned{cd.kind, cd.tile, cd.ksplit};
@@ -1445,8 +1493,8 @@ static int create_impl(demon_ctx **out, int device, int max_batch, int height, i
     p->d_scale = dev_alloc(p, sizeof(float) * max_batch);
     p->d_motion = dev_alloc(p, sizeof(float) * 7 * max_batch);
     p->d_intrinsics = dev_alloc(p, sizeof(float) * 4 * max_batch);
-    p->d_ws = dev_alloc(p, sizeof(float) * kSplitKWorkspaceFloats);
-    p->d_ws_side = dev_alloc(p, sizeof(float) * kSplitKWorkspaceFloats);
+    p->d_ws = alloc_splitk_workspace(p);
+    p->d_ws_side = alloc_splitk_workspace(p);
     if (hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking) != hipSuccess) p->side_stream = nullptr;
     p->events.clear();  // fork / join events are created on demand (next_event)
     if (!p->d_ws_side) p->d_ws_side = p->d_ws, p->opt_side_branches = 0;
@@ -1500,7 +1548,7 @@ int demon_create_ops(demon_ctx **out, int device)
     c->device = device; c->max_batch = 0; c->variant = 0; c->opt_side_branches = 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
         return fail(nullptr, DEMON_ERR_HIP, "hipStreamCreate failed");
-    c->d_ws = dev_alloc(c.get(), sizeof(float) * kSplitKWorkspaceFloats);
+    c->d_ws = alloc_splitk_workspace(c.get());
     c->d_ws_side = c->d_ws;
     if (!c->d_ws) {
         demon_destroy(c.release());
