@@ -26,7 +26,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // KW > 1: KW groups of WM x WN waves share the output tile and split its K range (each with its own LDS buffers, all meeting at the
 // same barriers); their accumulators are summed through LDS in group order at the end -- split-K without partial sums in HBM and
 // without a reduce launch, for the layers whose tiles are too few to fill the chip.
-template <int WM, int WN, int TM, int TN, int KS, int KW>
+// INL: the instantiation that combines split-K slices inside the launch (kept apart: its extra live registers cost the ordinary
+// kernels of the 64-row wave tiles a wave of occupancy when the code sits behind a run-time branch)
+template <int WM, int WN, int TM, int TN, int KS, int KW, bool INL>
 __global__ __launch_bounds__(64 * WM * WN * KW) void conv_frag_kernel(StreamArgs s)
 {
     const ConvArgs &a = s.c;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void conv_frag_kernel(StreamArgs
     const int mw = m0 + wm * TM * 32;
     const long pw = p0 + (long)wn * TN * 32;
     if (a.ksplit > 1) {
-        if (a.tickets) {  // combined inside this launch (internal.h)
+        if constexpr (INL) {  // combined inside this launch (internal.h)
             if (!splitk_combine_in_launch<TM, TN>(acc, a.ws, a.tickets, a.ksplit, cls, zs, WM * WN, wave)) return;
         } else {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
             float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
@@ -360,8 +362,8 @@ int frag_variant_bm(int v) { return 32 * kFragVariants[v].tm * kFragVariants[v].
 int frag_variant_bn(int v) { return 32 * kFragVariants[v].tn * kFragVariants[v].wn; }
 int frag_variant_kw(int v) { return kFragVariants[v].kw; }
 
-template <int WM, int WN, int TM, int TN, int KS, int KW>
-static void launch_frag_variant(const StreamArgs &s, dim3 grid, hipStream_t stream)
+template <int WM, int WN, int TM, int TN, int KS, int KW, bool INL>
+static void launch_frag_instance(const StreamArgs &s, dim3 grid, hipStream_t stream)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t tiles = sizeof(float) * KW * 2 * (KS * BM * 16 + KS * 16 * BN);
@@ -369,11 +371,18 @@ static void launch_frag_variant(const StreamArgs &s, dim3 grid, hipStream_t stre
     constexpr size_t lds = tiles > red ? tiles : red;
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
     if (lds > 48 * 1024) {  // more dynamic LDS than the default limit: opt in once per instantiation
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_kernel<WM, WN, TM, TN, KS, KW>),
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_kernel<WM, WN, TM, TN, KS, KW, INL>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)once;
     }
-    hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN, KS, KW>), grid, dim3(64 * WM * WN * KW), lds, stream, s);
+    hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN, KS, KW, INL>), grid, dim3(64 * WM * WN * KW), lds, stream, s);
+}
+
+template <int WM, int WN, int TM, int TN, int KS, int KW>
+static void launch_frag_variant(const StreamArgs &s, dim3 grid, hipStream_t stream)
+{
+    if (s.c.tickets) launch_frag_instance<WM, WN, TM, TN, KS, KW, true>(s, grid, stream);
+    else launch_frag_instance<WM, WN, TM, TN, KS, KW, false>(s, grid, stream);
 }
 
 bool launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)

@@ -29,7 +29,7 @@ namespace demon {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool INL>  // INL: split-K slices combined inside the launch (see conv_frag.hip)
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
 {
     constexpr int BK = 16;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     tl.mark(2);
 
     if (a.ksplit > 1) {
-        if (a.tickets) {  // combined inside this launch (internal.h)
+        if constexpr (INL) {  // combined inside this launch (internal.h)
             if (!splitk_combine_in_launch<TM, TN>(acc, a.ws, a.tickets, a.ksplit, cls, zs, WM * WN, tid >> 6)) return;
         } else {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
             float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
@@ -401,7 +401,8 @@ int conv_tile_bn(int tile) { return kTiles[tile].bn; }
 template <int BM, int BN, int WM, int WN>
 static void launch_tile(const ConvArgs &a, dim3 grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), 0, stream, a);
+    if (a.tickets) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, true>), grid, dim3(64 * WM * WN), 0, stream, a);
+    else hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, false>), grid, dim3(64 * WM * WN), 0, stream, a);
 }
 
 bool launch_conv_mfma(const ConvArgs &a_in, ConvPlan plan, int nclasses, hipStream_t stream)

@@ -18,7 +18,9 @@ namespace demon {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int K, int S, int MB1, int MB2>
+// C1 = input channels per K-step of phase 1: 2 (9 / 7 taps), 8 (3 taps), or 6 = the whole input of conv1 in ONE step (no
+// double buffer, no load / barrier round trips inside phase 1: a workgroup's lifetime is a chain of memory latencies)
+template <int K, int S, int MB1, int MB2, int C1>
 struct PairGeom {
     static constexpr int TH = 4, TW = 32;
     static constexpr int TWm = (TW - 1) * S + K;          // intermediate columns the tile needs
@@ -27,17 +29,18 @@ struct PairGeom {
     static constexpr int N1 = TH * TWp;                   // intermediate pixels (with pitch padding)
     static constexpr int NB1 = (N1 + 31) / 32;            // 32-pixel MFMA column blocks of phase 1
     static constexpr int NBW = (NB1 + 3) / 4;             // ... per wave
-    static constexpr int CKS1 = K == 3 ? 8 : 2;           // input channels per K-step of phase 1
+    static constexpr int CKS1 = C1;                       // input channels per K-step of phase 1
+    static constexpr bool ONE1 = C1 == 6;                 // phase 1 is a single K-step
     static constexpr int CKS2 = K == 3 ? 8 : 2;           // intermediate channels per K-step of phase 2
     static constexpr int KD1 = K * CKS1, KD2 = K * CKS2;
     static constexpr int PPS = PH * TWp;                  // patch plane
     static constexpr int PELEMS = CKS1 * PPS;
-    static constexpr int EPT = (PELEMS + 255) / 256;
+    static constexpr int EPP = (PPS + 255) / 256;         // patch positions per thread (each for CKS1 channels)
     static constexpr int A1CH = KD1 * MB1 * 8, A1PER = (A1CH + 255) / 256;  // float4 chunks of the phase-1 weight tile
     static constexpr int A2CH = KD2 * MB2 * 8, A2PER = (A2CH + 255) / 256;
     static constexpr int MS = N1;                         // mid plane stride
     static constexpr int MID = MB1 * 32 * MS;
-    static constexpr int STAGE1 = 2 * (KD1 * MB1 * 32 + PELEMS);
+    static constexpr int STAGE1 = (ONE1 ? 1 : 2) * (KD1 * MB1 * 32 + PELEMS);
     // phase-2 weights: the whole [K * CM][BM2] matrix stays in LDS when it is at most 40 KB (no K-steps, no barriers in phase 2);
     // otherwise tiles of CKS2 channels stream through a double buffer
     static constexpr int W2ALL = K * MB1 * 32 * MB2 * 32;
@@ -48,19 +51,20 @@ struct PairGeom {
     static constexpr size_t lds_bytes = sizeof(float) * (size_t)(MID + STAGE);
 };
 
-template <int K, int S, int MB1, int MB2>
+template <int K, int S, int MB1, int MB2, int C1>
 __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
 {
-    using G = PairGeom<K, S, MB1, MB2>;
+    using G = PairGeom<K, S, MB1, MB2, C1>;
     constexpr int TH = G::TH, TW = G::TW, TWm = G::TWm, TWp = G::TWp, N1 = G::N1, NB1 = G::NB1, NBW = G::NBW;
-    constexpr int CKS1 = G::CKS1, CKS2 = G::CKS2, KD1 = G::KD1, KD2 = G::KD2, PPS = G::PPS, PELEMS = G::PELEMS, EPT = G::EPT;
+    constexpr int CKS1 = G::CKS1, CKS2 = G::CKS2, KD1 = G::KD1, KD2 = G::KD2, PPS = G::PPS, PELEMS = G::PELEMS, EPP = G::EPP;
+    constexpr bool ONE1 = G::ONE1;
     constexpr int A1PER = G::A1PER, A2PER = G::A2PER, MS = G::MS;
     constexpr int BM1 = MB1 * 32, BM2 = MB2 * 32;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *mid = smem;                   // [BM1][MS]
     float *stage = smem + G::MID;        // phase 1: As[2][KD1][BM1], Ps[2][PELEMS]; phase 2: As[2][KD2][BM2]
-    float *As1 = stage, *Ps = stage + 2 * KD1 * BM1, *As2 = stage;
+    float *As1 = stage, *Ps = stage + (ONE1 ? 1 : 2) * KD1 * BM1, *As2 = stage;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -73,22 +77,20 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
     const int x_org = tx * TW * S - a.pw;   // intermediate (= input) column of patch / mid column 0
     const float *__restrict__ in0 = a.in + (long)n * a.in_n_stride;
 
-    // ---- phase 1 staging: patch element e = tid + i*256 of [CKS1][PH][TWp], decoded once
-    int goff[EPT];
-    unsigned okbits = 0, oklast = 0;
-    const int last_c0 = (a.steps1 - 1) * CKS1;
+    // ---- phase 1 staging: a thread owns patch positions pos = tid + i*256 of [PH][TWp], decoded once, for all CKS1 channels
+    int goff[EPP];
+    unsigned okbits = 0;
+    const int HW = a.H * a.W;
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-        const int e = tid + i * 256;
+    for (int i = 0; i < EPP; ++i) {
+        const int pos = tid + i * 256;
         goff[i] = 0;
-        if (e < PELEMS) {
-            const int c = e / PPS, pos = e - c * PPS;
+        if (pos < PPS) {
             const int py = pos / TWp, px = pos - py * TWp;
             const int gy = y_org + py, gx = x_org + px;
             const bool ok = (px < TWm) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
-            if (ok) goff[i] = c * a.H * a.W + gy * a.W + gx;
+            if (ok) goff[i] = gy * a.W + gx;
             okbits |= (ok ? 1u : 0u) << i;
-            oklast |= ((ok && last_c0 + c < a.Cin) ? 1u : 0u) << i;
         }
     }
     int a1off[A1PER];
@@ -98,23 +100,30 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
         const int r = q / (BM1 / 4), c4 = q - r * (BM1 / 4);
         a1off[i] = ((r / CKS1) * a.Cin + (r % CKS1)) * a.Mpad1 + c4 * 4;
     }
-    float preg[EPT];
+    float preg[CKS1][EPP];
     floatx4 areg[A1PER > A2PER ? A1PER : A2PER];
     auto load1 = [&](int step) {
-        const float *__restrict__ pb = in0 + (long)step * CKS1 * a.H * a.W;
         const float *__restrict__ ab = a.w1 + (long)step * CKS1 * a.Mpad1;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i)
-            if (tid + i * 256 < PELEMS) preg[i] = pb[goff[i]];
+        for (int c = 0; c < CKS1; ++c) {
+            const float *__restrict__ pb = in0 + (long)min(step * CKS1 + c, a.Cin - 1) * HW;  // channels past Cin: zeroed in store1
+#pragma unroll
+            for (int i = 0; i < EPP; ++i)
+                if (tid + i * 256 < PPS) preg[c][i] = pb[goff[i]];
+        }
 #pragma unroll
         for (int i = 0; i < A1PER; ++i)
             if (tid + i * 256 < G::A1CH) areg[i] = *reinterpret_cast<const floatx4 *>(ab + a1off[i]);
     };
-    auto store1 = [&](int buf, unsigned ok) {
+    auto store1 = [&](int buf, int step) {
         float *P = Ps + buf * PELEMS;
 #pragma unroll
-        for (int i = 0; i < EPT; ++i)
-            if (tid + i * 256 < PELEMS) P[tid + i * 256] = ((ok >> i) & 1u) ? preg[i] : 0.0f;
+        for (int c = 0; c < CKS1; ++c) {
+            const bool cok = step * CKS1 + c < a.Cin;
+#pragma unroll
+            for (int i = 0; i < EPP; ++i)
+                if (tid + i * 256 < PPS) P[c * PPS + tid + i * 256] = (cok && ((okbits >> i) & 1u)) ? preg[c][i] : 0.0f;
+        }
         float *A = As1 + buf * (KD1 * BM1);
 #pragma unroll
         for (int i = 0; i < A1PER; ++i)
@@ -139,11 +148,11 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
             for (int r = 0; r < 16; ++r) acc1[i][nb][r] = 0.0f;
 
     load1(0);
-    store1(0, a.steps1 == 1 ? oklast : okbits);
+    store1(0, 0);
     __syncthreads();
     for (int s = 0; s < a.steps1; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < a.steps1) load1(s + 1);
+        const int buf = ONE1 ? 0 : (s & 1);
+        if (!ONE1 && s + 1 < a.steps1) load1(s + 1);
         const char *Pb = reinterpret_cast<const char *>(Ps + buf * PELEMS);
         const float *A = As1 + buf * (KD1 * BM1);
 #pragma unroll
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
                 }
             }
         }
-        if (s + 1 < a.steps1) store1(buf ^ 1, (s + 1 == a.steps1 - 1) ? oklast : okbits);
+        if (!ONE1 && s + 1 < a.steps1) store1(buf ^ 1, s + 1);
         __syncthreads();
     }
 
@@ -293,20 +302,23 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(PairArgs a)
         }
 }
 
-template <int K, int S, int MB1, int MB2>
-static bool launch_pair_t(const PairArgs &a, hipStream_t s)
+template <int K, int S, int MB1, int MB2, int C1>
+static bool launch_pair_t(const PairArgs &a_in, hipStream_t s)
 {
-    using G = PairGeom<K, S, MB1, MB2>;
+    using G = PairGeom<K, S, MB1, MB2, C1>;
     static bool configured = false;
     if (!configured) {
         if (G::lds_bytes > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pair_kernel<K, S, MB1, MB2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pair_kernel<K, S, MB1, MB2, C1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)G::lds_bytes) != hipSuccess)
             return false;
         configured = true;
     }
+    PairArgs a = a_in;
+    a.steps1 = (a.Cin + C1 - 1) / C1;
+    a.steps2 = (a.CM + G::CKS2 - 1) / G::CKS2;
     dim3 grid((unsigned)(a.N * a.tiles_y * a.tiles_x));
-    hipLaunchKernelGGL((conv_pair_kernel<K, S, MB1, MB2>), grid, dim3(256), G::lds_bytes, s, a);
+    hipLaunchKernelGGL((conv_pair_kernel<K, S, MB1, MB2, C1>), grid, dim3(256), G::lds_bytes, s, a);
     return true;
 }
 
@@ -335,16 +347,22 @@ int conv_pair_cks(int k) { return k == 3 ? 8 : 2; }
 bool launch_conv_pair(const PairArgs &a, int k, int stride, hipStream_t s)
 {
     const int mb1 = (a.CM + 31) / 32, mb2 = (a.CO + 31) / 32;
-#define PAIR_CASE(KK, SS)                                                  \
-    if (k == KK && stride == SS) {                                         \
-        if (mb1 == 1 && mb2 == 1) return launch_pair_t<KK, SS, 1, 1>(a, s); \
-        if (mb1 == 1 && mb2 == 2) return launch_pair_t<KK, SS, 1, 2>(a, s); \
-        if (mb1 == 2 && mb2 == 1) return launch_pair_t<KK, SS, 2, 1>(a, s); \
-        return launch_pair_t<KK, SS, 2, 2>(a, s);                          \
+    // conv1 of every block: 6 input channels, 9 taps -> the whole phase-1 reduction in one K-step
+    static const int one_step = getenv("DEMON_PAIR_ONE_STEP") ? atoi(getenv("DEMON_PAIR_ONE_STEP")) : 1;
+    if (k == 9 && stride == 2 && a.Cin == 6 && mb1 == 1 && one_step) {
+        if (mb2 == 1) return launch_pair_t<9, 2, 1, 1, 6>(a, s);
+        return launch_pair_t<9, 2, 1, 2, 6>(a, s);
     }
-    PAIR_CASE(9, 2)
-    PAIR_CASE(7, 2)
-    PAIR_CASE(3, 1)
+#define PAIR_CASE(KK, SS, CC)                                                  \
+    if (k == KK && stride == SS) {                                             \
+        if (mb1 == 1 && mb2 == 1) return launch_pair_t<KK, SS, 1, 1, CC>(a, s); \
+        if (mb1 == 1 && mb2 == 2) return launch_pair_t<KK, SS, 1, 2, CC>(a, s); \
+        if (mb1 == 2 && mb2 == 1) return launch_pair_t<KK, SS, 2, 1, CC>(a, s); \
+        return launch_pair_t<KK, SS, 2, 2, CC>(a, s);                          \
+    }
+    PAIR_CASE(9, 2, 2)
+    PAIR_CASE(7, 2, 2)
+    PAIR_CASE(3, 1, 8)
 #undef PAIR_CASE
     return false;
 }

@@ -67,7 +67,8 @@ struct StreamSet {
 // KW > 1 (small batches: few output tiles, long K): KW groups of NW waves share the tile and split its K range between them;
 // their partial accumulators are summed through LDS at the end, in wave order -- split-K without partial sums in HBM and
 // without a reduce launch.
-template <int NW, int TM, int TN, int KW>
+// INL: the instantiation that combines split-K slices inside the launch (see conv_frag.hip)
+template <int NW, int TM, int TN, int KW, bool INL>
 __global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
 {
     const ConvArgs &a = s.c;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
 
     // ---- epilogue (as conv_mfma.hip)
     if (a.ksplit > 1) {
-        if (a.tickets) {  // combined inside this launch (internal.h)
+        if constexpr (INL) {  // combined inside this launch (internal.h)
             if (!splitk_combine_in_launch<TM, TN>(acc, a.ws, a.tickets, a.ksplit, cls, zs, NW, wave)) return;
         } else {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
             float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
@@ -360,7 +361,8 @@ template <int NW, int TM, int TN, int KW>
 static void launch_stream_variant(const StreamArgs &s, dim3 grid, hipStream_t stream)
 {
     const size_t lds = KW > 1 ? sizeof(float) * KW * NW * TM * TN * 16 * 64 : 0;
-    hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW>), grid, dim3(64 * NW * KW), lds, stream, s);
+    if (s.c.tickets) hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW, true>), grid, dim3(64 * NW * KW), lds, stream, s);
+    else hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW, false>), grid, dim3(64 * NW * KW), lds, stream, s);
 }
 
 bool launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
