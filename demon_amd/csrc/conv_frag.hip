@@ -29,7 +29,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // INL: the instantiation that combines split-K slices inside the launch (kept apart: its extra live registers cost the ordinary
 // kernels of the 64-row wave tiles a wave of occupancy when the code sits behind a run-time branch)
 template <int WM, int WN, int TM, int TN, int KS, int KW, bool INL>
-__global__ __launch_bounds__(64 * WM * WN * KW) void conv_frag_kernel(StreamArgs s)
+__device__ __forceinline__ void frag_tile(const StreamArgs &s)
 {
     const ConvArgs &a = s.c;
     TlScope tl(a.tl);
@@ -352,6 +352,27 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void conv_frag_kernel(StreamArgs
     }
 }
 
+template <int WM, int WN, int TM, int TN, int KS, int KW, bool INL>
+__global__ __launch_bounds__(64 * WM * WN * KW) void conv_frag_kernel(StreamArgs s)
+{
+    frag_tile<WM, WN, TM, TN, KS, KW, INL>(s);
+}
+
+// Two dependent layers in ONE launch: the k x 1 and the 1 x k conv of a stride-1 separable pair (helpers.py:105-153), when a
+// workgroup's tile holds ALL output channels (BM == Mpad) of WHOLE image rows (BN a multiple of the row length).  The 1 x k conv
+// of those rows then reads nothing but what this workgroup's k x 1 conv just wrote (same rows, columns +-k/2, every channel), so the
+// pair needs no grid-wide dependency: first layer, its stores drained and visible to the workgroup (they went through this CU's L1),
+// barrier, second layer on the same tile.  Same kernels, same order of operations as the two launches -> the same bits; what
+// disappears is a launch boundary with its drain / refill of the whole chip, and the workgroups stop marching in lock-step.
+template <int WM, int WN, int TM, int TN, int KS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_frag_chain_kernel(StreamArgs s1, StreamArgs s2)
+{
+    frag_tile<WM, WN, TM, TN, KS, 1, false>(s1);
+    __syncthreads();   // workgroup-scope release / acquire around the barrier: the first layer's stores are complete and visible
+    frag_tile<WM, WN, TM, TN, KS, 1, false>(s2);
+}
+
+
 struct FragVariant { int wm, wn, tm, tn, ks, kw; };
 static const FragVariant kFragVariants[FRAG_VARIANTS] = {
     {2, 2, 2, 1, 1, 1}, {2, 2, 1, 1, 1, 1}, {2, 2, 2, 2, 1, 1}, {2, 2, 1, 2, 1, 1}, {4, 1, 2, 1, 1, 1}, {1, 4, 2, 1, 1, 1}, {4, 1, 1, 1, 1, 1},
@@ -383,6 +404,54 @@ static void launch_frag_variant(const StreamArgs &s, dim3 grid, hipStream_t stre
 {
     if (s.c.tickets) launch_frag_instance<WM, WN, TM, TN, KS, KW, true>(s, grid, stream);
     else launch_frag_instance<WM, WN, TM, TN, KS, KW, false>(s, grid, stream);
+}
+
+template <int WM, int WN, int TM, int TN, int KS>
+static void launch_frag_chain_instance(const StreamArgs &s1, const StreamArgs &s2, dim3 grid, hipStream_t stream)
+{
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr size_t lds = sizeof(float) * 2 * (KS * BM * 16 + KS * 16 * BN);
+    if (lds > 48 * 1024) {
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_chain_kernel<WM, WN, TM, TN, KS>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)once;
+    }
+    hipLaunchKernelGGL((conv_frag_chain_kernel<WM, WN, TM, TN, KS>), grid, dim3(64 * WM * WN), lds, stream, s1, s2);
+}
+
+// true when the pair ran as one chained launch; false (nothing launched) when the variant / shapes do not allow it
+bool launch_conv_frag_chain(const StreamArgs &s1_in, const StreamArgs &s2_in, int variant, hipStream_t stream)
+{
+    if (variant < 0 || variant >= FRAG_VARIANTS || kFragVariants[variant].kw != 1) return false;
+    StreamArgs s1 = s1_in, s2 = s2_in;
+    s1.c.ksplit = s2.c.ksplit = 1;
+    s1.c.tickets = s2.c.tickets = nullptr;
+    const ConvArgs &a = s1.c, &b = s2.c;
+    const int bm = frag_variant_bm(variant), bn = frag_variant_bn(variant);
+    const bool same_grid = a.N == b.N && a.Hp == b.Hp && a.Wp == b.Wp && a.Mpad == b.Mpad;
+    if (!same_grid || a.Mpad != bm || bn % a.Wp != 0 || b.in != a.out || b.sy != 1 || b.sx != 1 || a.osx != 1 || a.osy != 1 || b.osx != 1 || b.osy != 1) return false;
+    // the second conv may only look sideways (1 x k): rows other than the tile's own belong to other workgroups
+    for (int t = 0; t < s2.ntaps; ++t)
+        if (s2.tapdy[0][t] != 0) return false;
+    const long P = (long)a.N * a.Hp * a.Wp;
+    dim3 grid((unsigned)((P + bn - 1) / bn), 1, 1);
+    switch (variant) {
+        case 0: launch_frag_chain_instance<2, 2, 2, 1, 1>(s1, s2, grid, stream); break;
+        case 1: launch_frag_chain_instance<2, 2, 1, 1, 1>(s1, s2, grid, stream); break;
+        case 2: launch_frag_chain_instance<2, 2, 2, 2, 1>(s1, s2, grid, stream); break;
+        case 3: launch_frag_chain_instance<2, 2, 1, 2, 1>(s1, s2, grid, stream); break;
+        case 4: launch_frag_chain_instance<4, 1, 2, 1, 1>(s1, s2, grid, stream); break;
+        case 5: launch_frag_chain_instance<1, 4, 2, 1, 1>(s1, s2, grid, stream); break;
+        case 6: launch_frag_chain_instance<4, 1, 1, 1, 1>(s1, s2, grid, stream); break;
+        case 7: launch_frag_chain_instance<1, 4, 2, 2, 1>(s1, s2, grid, stream); break;
+        case 8: launch_frag_chain_instance<2, 2, 1, 1, 2>(s1, s2, grid, stream); break;
+        case 9: launch_frag_chain_instance<4, 1, 1, 1, 2>(s1, s2, grid, stream); break;
+        case 10: launch_frag_chain_instance<2, 2, 2, 1, 2>(s1, s2, grid, stream); break;
+        case 11: launch_frag_chain_instance<1, 4, 2, 1, 2>(s1, s2, grid, stream); break;
+        case 12: launch_frag_chain_instance<2, 2, 1, 2, 2>(s1, s2, grid, stream); break;
+        default: launch_frag_chain_instance<1, 4, 1, 1, 2>(s1, s2, grid, stream); break;
+    }
+    return true;
 }
 
 bool launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)

@@ -69,7 +69,7 @@ struct StreamSet {
 // without a reduce launch.
 // INL: the instantiation that combines split-K slices inside the launch (see conv_frag.hip)
 template <int NW, int TM, int TN, int KW, bool INL>
-__global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
+__device__ __forceinline__ void stream_tile(const StreamArgs &s)
 {
     const ConvArgs &a = s.c;
     TlScope tl(a.tl);
@@ -346,6 +346,23 @@ __global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
     }
 }
 
+template <int NW, int TM, int TN, int KW, bool INL>
+__global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
+{
+    stream_tile<NW, TM, TN, KW, INL>(s);
+}
+
+// the k x 1 and the 1 x k conv of a stride-1 separable pair in one launch (see conv_frag_chain_kernel, conv_frag.hip): the NW waves
+// of a workgroup hold all output channels of whole image rows; the barrier between the layers is the only one in this kernel
+template <int NW, int TM, int TN>
+__global__ __launch_bounds__(64 * NW) void conv_stream_chain_kernel(StreamArgs s1, StreamArgs s2)
+{
+    stream_tile<NW, TM, TN, 1, false>(s1);
+    __syncthreads();
+    stream_tile<NW, TM, TN, 1, false>(s2);
+}
+
+
 struct StreamVariant { int nw, tm, tn, kw; };
 // (waves along Cout, 32-channel row blocks per wave, 32-pixel column blocks per wave, K-splitting wave groups per workgroup)
 static const StreamVariant kStreamVariants[STREAM_VARIANTS] = {
@@ -363,6 +380,35 @@ static void launch_stream_variant(const StreamArgs &s, dim3 grid, hipStream_t st
     const size_t lds = KW > 1 ? sizeof(float) * KW * NW * TM * TN * 16 * 64 : 0;
     if (s.c.tickets) hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW, true>), grid, dim3(64 * NW * KW), lds, stream, s);
     else hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW, false>), grid, dim3(64 * NW * KW), lds, stream, s);
+}
+
+bool launch_conv_stream_chain(const StreamArgs &s1_in, const StreamArgs &s2_in, int variant, hipStream_t stream)
+{
+    if (variant < 0 || variant >= STREAM_VARIANTS || kStreamVariants[variant].kw != 1) return false;
+    StreamArgs s1 = s1_in, s2 = s2_in;
+    s1.c.ksplit = s2.c.ksplit = 1;
+    s1.c.tickets = s2.c.tickets = nullptr;
+    const ConvArgs &a = s1.c, &b = s2.c;
+    const int bm = stream_variant_bm(variant), bn = stream_variant_bn(variant);
+    const bool same_grid = a.N == b.N && a.Hp == b.Hp && a.Wp == b.Wp && a.Mpad == b.Mpad;
+    if (!same_grid || a.Mpad != bm || bn % a.Wp != 0 || b.in != a.out || b.sy != 1 || b.sx != 1 || a.osx != 1 || a.osy != 1 || b.osx != 1 || b.osy != 1) return false;
+    for (int t = 0; t < s2.ntaps; ++t)
+        if (s2.tapdy[0][t] != 0) return false;
+    const long P = (long)a.N * a.Hp * a.Wp;
+    dim3 grid((unsigned)((P + bn - 1) / bn), 1, 1);
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((conv_stream_chain_kernel<4, 1, 1>), grid, dim3(256), 0, stream, s1, s2); break;
+        case 1: hipLaunchKernelGGL((conv_stream_chain_kernel<4, 1, 2>), grid, dim3(256), 0, stream, s1, s2); break;
+        case 2: hipLaunchKernelGGL((conv_stream_chain_kernel<2, 1, 1>), grid, dim3(128), 0, stream, s1, s2); break;
+        case 3: hipLaunchKernelGGL((conv_stream_chain_kernel<2, 1, 2>), grid, dim3(128), 0, stream, s1, s2); break;
+        case 4: hipLaunchKernelGGL((conv_stream_chain_kernel<1, 1, 1>), grid, dim3(64), 0, stream, s1, s2); break;
+        case 5: hipLaunchKernelGGL((conv_stream_chain_kernel<1, 1, 2>), grid, dim3(64), 0, stream, s1, s2); break;
+        case 6: hipLaunchKernelGGL((conv_stream_chain_kernel<2, 2, 2>), grid, dim3(128), 0, stream, s1, s2); break;
+        case 7: hipLaunchKernelGGL((conv_stream_chain_kernel<1, 2, 2>), grid, dim3(64), 0, stream, s1, s2); break;
+        case 8: hipLaunchKernelGGL((conv_stream_chain_kernel<2, 2, 1>), grid, dim3(128), 0, stream, s1, s2); break;
+        default: hipLaunchKernelGGL((conv_stream_chain_kernel<4, 2, 1>), grid, dim3(256), 0, stream, s1, s2); break;
+    }
+    return true;
 }
 
 bool launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)

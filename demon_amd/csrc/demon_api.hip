@@ -80,6 +80,8 @@ struct Step {
     // k x 1 / 1 x k pairs that conv_pair.hip can run as one launch exist twice in the list: pair = 1 is the fused step (runs when
     // option fused_pairs is on), pair = 2 marks the two ordinary layer steps (run when it is off)
     int pair = 0;
+    // empty: the fused form always applies (conv_pair.hip); else: decided per batch size by the launch plan (chained pairs)
+    std::function<bool(int n)> pair_applies;
     // Side branch: small kernel chains that do not depend on the steps that follow them on the main stream (the motion head next
     // to the decoder of the depth+motion block, predict_flow5 -> upsample next to refine4 of the flow block) run on a second
     // stream.  side = 1 marks them; fork = 1 on the first one (side stream waits for everything enqueued so far on the main
@@ -129,6 +131,7 @@ struct demon_ctx {
     float *w_slab = nullptr;
     size_t w_slab_floats = 0;
     float *d_zero = nullptr;  // shared zero page of the conv_stream layers
+    std::vector<std::pair<Layer *, Layer *>> chain_pairs;  // stride-1 k x 1 / 1 x k pairs that can run as one chained launch
 };
 
 namespace {
@@ -679,12 +682,13 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 run_small(L, a, s);
                 return;
             }
-            if (t.kind == 4 && L->stream_ok() && L->Mpad % stream_variant_bm(t.tile) == 0) {
-                run_stream(L, a, t.tile, clamp_split(t.ksplit), s);
+            // kinds 6 / 7 = chained with the 1 x k partner (run_chain); reached here only when the chain did not apply
+            if ((t.kind == 4 || t.kind == 7) && L->stream_ok() && L->Mpad % stream_variant_bm(t.tile) == 0) {
+                run_stream(L, a, t.tile, t.kind == 7 ? 1 : clamp_split(t.ksplit), s);
                 return;
             }
-            if (t.kind == 5 && L->stream_ok() && L->Mpad % frag_variant_bm(t.tile) == 0) {
-                run_frag(L, a, t.tile, clamp_split(t.ksplit), s);
+            if ((t.kind == 5 || t.kind == 6) && L->stream_ok() && L->Mpad % frag_variant_bm(t.tile) == 0) {
+                run_frag(L, a, t.tile, t.kind == 6 ? 1 : clamp_split(t.ksplit), s);
                 return;
             }
             if (t.kind == 1) {
@@ -872,6 +876,47 @@ bool run_pair(const Layer *Ly, const Layer *Lx, int n, hipStream_t s)
     return true;
 }
 
+// ---- chained pairs: the k x 1 and the 1 x k conv of a stride-1 pair as ONE launch (conv_frag_chain_kernel / conv_stream_chain_kernel)
+// when a workgroup tile of the chosen variant holds all channels of whole rows.  The plan of the k x 1 layer says so: kind 6 =
+// chained on conv_frag variant `tile`, kind 7 = on conv_stream variant `tile`.
+bool chain_shape_ok(const Layer *Ly, const Layer *Lx, int kind, int v)
+{
+    if (!Ly->stream_ok() || !Lx->stream_ok() || Ly->kind != Layer::CONV || Lx->kind != Layer::CONV) return false;
+    if (Ly->sh != 1 || Ly->sw != 1 || Lx->sh != 1 || Lx->sw != 1 || Lx->kh != 1 || Ly->Mpad != Lx->Mpad) return false;
+    if (Ly->out.H != Lx->out.H || Ly->out.W != Lx->out.W || Ly->scale || Lx->scale) return false;
+    if (kind == 6) return v >= 0 && v < FRAG_VARIANTS && frag_variant_kw(v) == 1 && frag_variant_bm(v) == Ly->Mpad && frag_variant_bn(v) % Ly->out.W == 0;
+    if (kind == 7) return v >= 0 && v < STREAM_VARIANTS && stream_variant_kw(v) == 1 && stream_variant_bm(v) == Ly->Mpad && stream_variant_bn(v) % Ly->out.W == 0;
+    return false;
+}
+
+bool chain_choice(const Layer *Ly, const Layer *Lx, int n, int &kind, int &v)
+{
+    if (const char *fp = getenv("DEMON_FORCE_PLAN")) {  // test hook: "6,v,1" / "7,v,1" chain every pair the variant fits; other plans: no chains
+        int ks = 0;
+        if (sscanf(fp, "%d,%d,%d", &kind, &v, &ks) == 3) return (kind == 6 || kind == 7) && chain_shape_ok(Ly, Lx, kind, v);
+    }
+    auto it = Ly->tuned.find(n);
+    if (it == Ly->tuned.end()) return false;
+    kind = it->second.kind;
+    v = it->second.tile;
+    return (kind == 6 || kind == 7) && chain_shape_ok(Ly, Lx, kind, v);
+}
+
+bool run_chain(const Layer *Ly, const Layer *Lx, int n, int kind, int v, hipStream_t s, float *ws)
+{
+    ConvArgs a1, a2;
+    fill_conv_args(Ly, n, ws, a1);
+    fill_conv_args(Lx, n, ws, a2);
+    StreamArgs s1, s2;
+    fill_stream_args(Ly, a1, 1, s1, s);
+    fill_stream_args(Lx, a2, 1, s2, s);
+    if (!(kind == 6 ? launch_conv_frag_chain(s1, s2, v, s) : launch_conv_stream_chain(s1, s2, v, s))) return false;
+    if (kind == 6) snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_frag_chain<%dx%d,v%d>", frag_variant_bm(v), frag_variant_bn(v), v);
+    else snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_stream_chain<%dx%d,w%d>", stream_variant_bm(v), stream_variant_bn(v), stream_variant_waves(v));
+    g_last_kernel = g_kernel_tag;
+    return true;
+}
+
 // ---- topology builder ---------------------------------------------------------------------------------
 struct Builder {
     demon_ctx *c;
@@ -939,7 +984,10 @@ struct Builder {
         View mid = buffer(c, key, cy, Hmid, in.W);
         // large maps with few channels (levels 1-2): one fused launch for the pair (conv_pair.hip) when the option is on
         const bool fusable = conv_pair_applies(k, s, in.C, cy, out.C) && (long)out.H * out.W >= 2048;
-        if (!fusable) {
+        // stride-1 pairs of the deeper levels: one chained launch when the launch plan says so (run_chain)
+        const bool chainable = !fusable && s == 1 && Layer::stream_shape_ok(Layer::CONV, in.C, k, 1) && Layer::stream_shape_ok(Layer::CONV, cy, 1, k) &&
+                               (cy + 31) / 32 == (out.C + 31) / 32;
+        if (!fusable && !chainable) {
             make(name + "y", Layer::CONV, in, mid, k, 1, s, 1, 1);
             make(name + "x", Layer::CONV, mid, out, 1, k, 1, s, 1);
             return;
@@ -955,11 +1003,25 @@ struct Builder {
         st.bytes_per_sample = 4.0 * ((double)in.C * in.H * in.W + (double)out.C * out.H * out.W);
         st.bytes_fixed = 4.0 * ((double)Ly->K * Ly->Cout + (double)Lx->K * Lx->Cout + Ly->Cout + Lx->Cout);
         float *ws = side ? c->d_ws_side : c->d_ws;
-        st.fn = [Ly, Lx, ws](int n, hipStream_t s2) {
-            if (run_pair(Ly, Lx, n, s2)) return;
-            run_layer(Ly, n, s2, ws);
-            run_layer(Lx, n, s2, ws);
-        };
+        std::function<bool(int)> applies;
+        if (chainable) {
+            c->chain_pairs.push_back({Ly, Lx});
+            applies = [Ly, Lx](int n) { int kind, v; return chain_choice(Ly, Lx, n, kind, v); };
+            st.bytes_per_sample += 8.0 * (double)cy * Hmid * in.W;  // the intermediate is still written, and read back out of L2
+            st.fn = [Ly, Lx, ws](int n, hipStream_t s2) {
+                int kind, v;
+                if (chain_choice(Ly, Lx, n, kind, v) && run_chain(Ly, Lx, n, kind, v, s2, ws)) return;
+                run_layer(Ly, n, s2, ws);
+                run_layer(Lx, n, s2, ws);
+            };
+        } else {
+            st.fn = [Ly, Lx, ws](int n, hipStream_t s2) {
+                if (run_pair(Ly, Lx, n, s2)) return;
+                run_layer(Ly, n, s2, ws);
+                run_layer(Lx, n, s2, ws);
+            };
+        }
+        st.pair_applies = applies;
         st.image_only = tag;
         st.pair = 1;
         join_next = jn; fork_next = fk;
@@ -975,6 +1037,7 @@ struct Builder {
             sl.fn = [L, ws](int n, hipStream_t s2) { run_layer(L, n, s2, ws); };
             sl.image_only = tag;
             sl.pair = 2;
+            sl.pair_applies = applies;
             if (L == Ly) { join_next = jn; fork_next = fk; }  // the same fork / join as the fused form
             stamp(sl);
             steps->push_back(sl);
@@ -1323,6 +1386,14 @@ bool stream_wait(demon_ctx *c, hipStream_t src, hipStream_t dst, size_t &ev)
     return false;
 }
 
+// of a k x 1 / 1 x k pair either the fused step (pair == 1) or its two layer steps (pair == 2) run
+bool pair_step_skipped(const demon_ctx *c, const Step &st, int n)
+{
+    if (!st.pair) return false;
+    const bool fused = c->opt_fused_pairs && (!st.pair_applies || st.pair_applies(n));
+    return st.pair == 1 ? !fused : fused;
+}
+
 void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t s, int mode, size_t &ev)
 {
     bool branches = c->opt_side_branches && c->side_stream && s == c->stream;
@@ -1331,7 +1402,7 @@ void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t 
         if (st.image_only == 1 && mode == 2) continue;
         if (st.image_only == 2 && mode != 2) continue;
         if (st.image_only == 3 && mode != 1) continue;
-        if ((st.pair == 1 && !c->opt_fused_pairs) || (st.pair == 2 && c->opt_fused_pairs)) continue;
+        if (pair_step_skipped(c, st, n)) continue;
         if ((st.fused == 1 && !c->opt_fused_inputs) || (st.fused == 2 && c->opt_fused_inputs)) continue;
         if (!branches) { st.fn(n, s); continue; }
         if (st.fork) {
@@ -1766,6 +1837,50 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }
 
+// A chainable pair: the two separately tuned launches against every chained variant that fits; the k x 1 layer's plan becomes
+// kind 6 / 7 when a chain is faster.
+int autotune_chain(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
+{
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;
+    bool failed = false;
+    auto measure = [&](const std::function<void()> &body) -> float {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            for (int i = 0; i < 5; ++i) body();
+            ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        }
+        if (ok) {
+            hipGraphLaunch(exec, c->stream);  // warm-up
+            hipEventRecord(e0, c->stream);
+            hipGraphLaunch(exec, c->stream);
+            hipEventRecord(e1, c->stream);
+            ok = hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess;
+        }
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph) hipGraphDestroy(graph);
+        if (!ok) { failed = true; return 1e30f; }
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        return ms;
+    };
+    float best = measure([&] { run_layer(Ly, n, c->stream, c->d_ws); run_layer(Lx, n, c->stream, c->d_ws); });
+    Layer::Tuned best_t{-1, 0, 0};
+    for (int kind : {6, 7})
+        for (int v = 0; v < (kind == 6 ? (int)FRAG_VARIANTS : (int)STREAM_VARIANTS) && !failed; ++v) {
+            if (!chain_shape_ok(Ly, Lx, kind, v)) continue;
+            const float ms = measure([&] { run_chain(Ly, Lx, n, kind, v, c->stream, c->d_ws); });
+            if (ms < best) { best = ms; best_t = Layer::Tuned{kind, v, 1}; }
+        }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (failed) return DEMON_ERR_HIP;
+    if (best_t.kind > 0) Ly->tuned[n] = best_t;
+    return DEMON_OK;
+}
+
 int demon_autotune(demon_ctx *c, int n)
 {
     if (!c || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "batch size out of range [1, max_batch]");
@@ -1776,6 +1891,10 @@ int demon_autotune(demon_ctx *c, int n)
     for (auto &L : c->layers) {
         int r = autotune_layer(c, L.get(), n);
         if (r) return fail(c, r, "autotune failed at layer " + L->name);
+    }
+    for (auto &pr : c->chain_pairs) {
+        int r = autotune_chain(c, pr.first, pr.second, n);
+        if (r) return fail(c, r, "autotune failed at pair " + pr.first->name);
     }
     return DEMON_OK;
 }
@@ -1798,8 +1917,9 @@ int demon_plan_get(const demon_ctx *c, int n, int layer_index, char *name, int n
 int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int tile, int ksplit)
 {
     if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
-    if (kind < 0 || kind > 5 || kind == 2 || tile < 0 ||
-        tile >= (kind == 1 ? (int)PTILE_COUNT : (kind == 4 ? (int)STREAM_VARIANTS : (kind == 5 ? (int)FRAG_VARIANTS : (int)TILE_COUNT))) || ksplit < 0)
+    // kinds: 0 im2col, 1 patch-staged, 3 small-Cout, 4 streaming, 5 fragment-tiled, 6 / 7 = kind 5 / 4 chained with the 1 x k partner
+    if (kind < 0 || kind > 7 || kind == 2 || tile < 0 ||
+        tile >= (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
@@ -1807,6 +1927,11 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             if (kind == 4 && (!L->stream_ok() || L->Mpad % stream_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the streaming kernel does not apply to this layer");
             if (kind == 5 && (!L->stream_ok() || L->Mpad % frag_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the fragment-tiled kernel does not apply to this layer");
+            if (kind == 6 || kind == 7) {
+                bool ok = false;
+                for (auto &pr : c->chain_pairs) ok = ok || (pr.first == L.get() && chain_shape_ok(pr.first, pr.second, kind, tile));
+                if (!ok) return fail(c, DEMON_ERR_INVALID, "this layer cannot run chained with a 1 x k partner on that variant");
+            }
             for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
             c->graphs.clear();
             L->tuned[n] = Layer::Tuned{kind, tile, (kind == 0 || kind == 4 || kind == 5) && ksplit < 1 ? 1 : ksplit};
@@ -1979,8 +2104,8 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
     // exactly the steps a default forward pass launches (run_steps, mode 0): of the k x 1 / 1 x k pairs either the fused step or
     // the two layer steps, never both; the image-feature cache steps only exist with reuse_image_features
     std::vector<const Step *> seq;
-    auto active = [c](const Step &s) {
-        return s.image_only < 2 && !((s.pair == 1 && !c->opt_fused_pairs) || (s.pair == 2 && c->opt_fused_pairs)) &&
+    auto active = [c, n](const Step &s) {
+        return s.image_only < 2 && !pair_step_skipped(c, s, n) &&
                !((s.fused == 1 && !c->opt_fused_inputs) || (s.fused == 2 && c->opt_fused_inputs));
     };
     for (auto &s : c->net_boot) if (active(s)) seq.push_back(&s);

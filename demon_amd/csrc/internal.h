@@ -211,6 +211,8 @@ int stream_variant_bm(int v);
 int stream_variant_bn(int v);
 void launch_stream_repack(float *wf, const float *wp, int ncls, int K, int Mpad, long cls_w_stride, hipStream_t s);
 bool launch_conv_stream(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
+// k x 1 + 1 x k stride-1 pair as one chained launch of a variant whose tile holds all channels of whole rows; false: not applicable
+bool launch_conv_stream_chain(const StreamArgs &s1, const StreamArgs &s2, int variant, hipStream_t stream);
 
 // ---- LDS-tiled contraction on fragment-ordered weights (conv_frag.hip; same arguments as the streaming kernel) -----------------
 constexpr int FRAG_VARIANTS = 22;  // (waves along Cout, waves along pixels, row blocks per wave, column blocks per wave)
@@ -218,6 +220,7 @@ int frag_variant_bm(int v);
 int frag_variant_bn(int v);
 int frag_variant_kw(int v);  // K-splitting wave groups inside a workgroup (1: none)
 bool launch_conv_frag(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
+bool launch_conv_frag_chain(const StreamArgs &s1, const StreamArgs &s2, int variant, hipStream_t stream);
 
 // ---- patch-staged convolution (conv_patch.hip) ---------------------------------------------------------
 constexpr int PATCH_EPT = 8;  // patch elements a thread stages per K-step

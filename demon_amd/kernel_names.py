@@ -33,6 +33,18 @@ def kernel_tag(name):
     if m:
         nw, tm, tn, kw = map(int, m.groups())
         return "conv_stream<%dx%d,w%dk%d>" % (32 * nw * tm, 32 * tn, nw, kw)
+    m = re.search(r"conv_frag_chain_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        params = tuple(map(int, m.groups())) + (1,)
+        wm, wn, tm, tn = params[:4]
+        for v, p in sorted(frag_variants().items()):
+            if p == params:
+                return "conv_frag_chain<%dx%d,v%d>" % (32 * tm * wm, 32 * tn * wn, v)
+        return "conv_frag_chain<%dx%d,?>" % (32 * tm * wm, 32 * tn * wn)
+    m = re.search(r"conv_stream_chain_kernel<(\d+), (\d+), (\d+)", name)
+    if m:
+        nw, tm, tn = map(int, m.groups())
+        return "conv_stream_chain<%dx%d,w%d>" % (32 * nw * tm, 32 * tn, nw)
     m = re.search(r"conv_frag_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
     if m:
         params = tuple(map(int, m.groups()))
@@ -64,6 +76,14 @@ def rocprof_kernel_name(tag):
         w, k = rest.rstrip(">").split(",")[1].lstrip("w").split("k")
         tm = int(dims[0]) // (32 * int(w))
         return "demon::conv_stream_kernel<%s, %d, %d, %s> (%sx%s tile)" % (w, tm, int(dims[1]) // 32, k, dims[0], dims[1])
+    if fam == "conv_stream_chain" and len(dims) == 2:
+        w = int(rest.rstrip(">").split(",w")[-1])
+        return "demon::conv_stream_chain_kernel<%d, %d, %d> (%sx%s tile)" % (w, int(dims[0]) // (32 * w), int(dims[1]) // 32, dims[0], dims[1])
+    if fam == "conv_frag_chain" and len(dims) == 2:
+        v = rest.rstrip(">").split(",v")[-1]
+        p = frag_variants().get(int(v)) if v.isdigit() else None
+        if p:
+            return "demon::conv_frag_chain_kernel<%d, %d, %d, %d, %d> (%sx%s tile)" % (p[:5] + (dims[0], dims[1]))
     if fam == "conv_frag" and len(dims) == 2:
         v = rest.rstrip(">").split(",v")[-1]
         p = frag_variants().get(int(v)) if v.isdigit() else None

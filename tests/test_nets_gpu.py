@@ -472,3 +472,35 @@ np.savez(OUT, depth0=result['predict_depth0'], rotation=rotation, translation=tr
     np.testing.assert_array_equal(res["translation"], want["predict_translation"])
     assert np.isfinite(res["depth0"]).all() and res["depth0"].shape == (1, 1, 192, 256)
     assert not np.array_equal(res["other_depth2"], res["boot_depth2"])    # session2's nets ran on session2's weights
+
+
+def test_chained_pairs_equal_the_two_launches(synth_weights):
+    """conv2_1 / conv3_1 / conv4_1: k x 1 and 1 x k conv as ONE chained launch (plan kinds 6 / 7: conv_frag_chain_kernel /
+    conv_stream_chain_kernel, a workgroup holds all channels of whole rows) against the two launches of the same kernel variant:
+    bit for bit, for every variant that fits, and the profile shows the chained kernel really ran"""
+    from demon_amd import DemonContext
+    n = 3
+    pair, img2_2 = make_inputs(n, seed=23)
+    ctx = DemonContext(device=0, max_batch=n, height=192, width=256)
+    try:
+        ctx.set_weights(synth_weights)
+        cases = {"conv2_1": [(5, 1), (5, 3), (5, 5), (5, 8), (5, 11), (4, 3), (4, 7)],
+                 "conv3_1": [(5, 0), (5, 2), (5, 6), (5, 9), (5, 10), (4, 0), (4, 1), (4, 6), (4, 8)],
+                 "conv4_1": [(5, 4), (4, 9)]}
+        for pairname, variants in cases.items():
+            for kind, v in variants:
+                names = ["%s/%s" % (net, pairname) for net in ("netFlow1", "netDM1")]
+                ctx.set_plan(n, {nm + ax: [kind, v, 1] for nm in names for ax in "yx"})
+                two = ctx.bootstrap(pair, img2_2)
+                ctx.set_plan(n, {nm + "y": [kind + 1 if kind == 5 else 7, v, 1] for nm in names})
+                one = ctx.bootstrap(pair, img2_2)
+                for k in two:
+                    np.testing.assert_array_equal(one[k], two[k], err_msg="%s kind %d variant %d: %s" % (pairname, kind, v, k))
+                tags = {r["name"]: r["kernel"] for r in ctx.profile_full(n, iterations=0, repeats=1)}
+                assert "chain" in tags[names[0] + "y+x"], tags.get(names[0] + "y+x")
+                assert names[0] + "y" not in tags
+        # a variant whose tile does not hold all channels of whole rows is refused
+        with pytest.raises(Exception):
+            ctx.set_plan(n, {"netFlow1/conv2_1y": [6, 6, 1]})
+    finally:
+        ctx.close()
