@@ -253,7 +253,7 @@ def main():
             }
             fam_achieved = flops / (ms * 1e-3) / 1e12
             result["roofline_family"] = {
-                "kernel": "all conv / deconv / dense launches (conv_frag, conv_stream, conv_patch, deconv4, conv_pair, conv_mfma, conv_small kernels)",
+                "kernel": "all conv / deconv / dense launches (conv_frag, conv_frag_chain, conv_stream, conv_stream_chain, conv_patch, deconv4, conv_pair, conv_mfma, conv_small kernels)",
                 "bound": "mfma", "achieved": fam_achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": fam_achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                 "algorithmic_bytes_per_launch": sum(r["bytes"] for r in conv) / len(conv),

@@ -96,9 +96,12 @@ int demon_set_option(demon_ctx *ctx, const char *key, int value);
 /* Times every applicable kernel variant (im2col / patch-staged, tile shape, split-K) of every layer at batch n on
  * this GPU and keeps the fastest per layer (~1 s; results do not change, only launch plans). */
 int demon_autotune(demon_ctx *ctx, int n);
-/* read back / install launch plans (kind 0 = im2col kernel, 1 = patch-staged kernel, 3 = small-Cout VALU kernel, 4 = register-
- * streaming kernel; tile id; split-K), e.g. to ship
- * the result of one autotune run as a file.  demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
+/* read back / install launch plans, e.g. to ship the result of one autotune run as a file.  Entry = (kind, tile, ksplit):
+ *   kind 0 im2col kernel (conv_mfma.hip), 1 patch-staged kernel (conv_patch.hip; ksplit + 1000 * (pixel-tile shape + 1)),
+ *        3 small-Cout VALU kernel, 4 register-streaming kernel (conv_stream.hip), 5 fragment-tiled kernel (conv_frag.hip),
+ *        6 / 7 on the k x 1 layer of a stride-1 pair: the pair runs as ONE chained launch of conv_frag / conv_stream variant `tile`;
+ *   tile = tile / variant id of that kernel; ksplit = K slices (kinds 0 / 4 / 5: + 1000 = slices combined inside the launch
+ *   instead of by a reduce launch).  demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
 int demon_num_layers(const demon_ctx *ctx);
 int demon_plan_get(const demon_ctx *ctx, int n, int layer_index, char *name, int name_cap, int *kind, int *tile, int *ksplit);
 int demon_plan_set(demon_ctx *ctx, int n, const char *layer_name, int kind, int tile, int ksplit);

@@ -82,3 +82,47 @@ def test_drop_in_module_path_exports_the_three_classes():
     R = angleaxis_to_rotation_matrix(np.array([-0.03653, 0.26291, 0.06665]))
     g = np.load(os.path.join(ROOT, "tests", "golden", "sculpture_geometry.npz"))
     np.testing.assert_allclose(R, g["Rt2"][:, :3], atol=2e-5)
+
+
+def test_shipped_plans_are_well_formed():
+    """demon_amd/tuned/*.json: every entry is (kind, tile, ksplit) of a kernel family that exists, a chained pair (kind 6 / 7 on the
+    k x 1 layer) has its 1 x k partner in the plan, and split-K stays on the reduce launch in the shipped plans"""
+    import glob
+    import json
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "demon_amd")
+    src = open(os.path.join(root, "csrc", "internal.h")).read()
+    limits = {0: 8, 1: 9, 3: 1, 4: int(re.search(r"STREAM_VARIANTS\s*=\s*(\d+)", src).group(1)), 5: int(re.search(r"FRAG_VARIANTS\s*=\s*(\d+)", src).group(1))}
+    limits[6], limits[7] = limits[5], limits[4]
+    files = sorted(glob.glob(os.path.join(root, "tuned", "plan_*.json")))
+    assert files
+    for f in files:
+        d = json.load(open(f))
+        assert d["plan"] and d["batch"] >= 1 and d["height"] % 32 == 0 and d["width"] % 32 == 0, f
+        for name, (kind, tile, ks) in d["plan"].items():
+            assert kind in limits and 0 <= tile < limits[kind] and ks >= 0, (f, name)
+            if kind in (0, 4, 5):
+                assert 1 <= ks < 1000, (f, name)
+            if kind in (6, 7):
+                assert name.endswith("y") and name[:-1] + "x" in d["plan"] and ks == 1, (f, name)
+
+
+def test_kernel_names_round_trip():
+    """profile tags <-> rocprofv3 template names (bench.py joins its hip-event table with profiles/*_kernel_stats.csv on them)"""
+    from demon_amd.kernel_names import frag_variants, kernel_tag, rocprof_kernel_name
+    assert len(frag_variants()) == 22
+    cases = {
+        "void demon::conv_frag_kernel<4, 1, 1, 1, 1, 1, false>(demon::StreamArgs)": "conv_frag<128x32,v6>",
+        "void demon::conv_frag_chain_kernel<1, 4, 2, 1, 1>(demon::StreamArgs, demon::StreamArgs)": "conv_frag_chain<64x128,v5>",
+        "void demon::conv_stream_chain_kernel<4, 2, 1>(demon::StreamArgs, demon::StreamArgs)": "conv_stream_chain<256x32,w4>",
+        "void demon::conv_stream_kernel<4, 2, 1, 1, false>(demon::StreamArgs)": "conv_stream<256x32,w4k1>",
+        "void demon::conv_patch_kernel<64, 2, 2, 1, 1, 4, 4, 2>(demon::PatchArgs)": "conv_patch<64x64,t4>",
+        "void demon::conv_mfma_kernel<128, 32, 4, 1, false>(demon::ConvArgs)": "conv_mfma<128x32>",
+        "void demon::deconv4_kernel<32, 1, 4, 4>(demon::PatchArgs)": "deconv4<32x128>",
+    }
+    for name, tag in cases.items():
+        assert kernel_tag(name) == tag
+        shown = rocprof_kernel_name(tag + "+splitk")
+        assert shown.split("<")[0] == "demon::" + tag.split("<")[0] + "_kernel"
+        assert shown.split("<")[0].replace("demon::", "") in name
