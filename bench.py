@@ -93,6 +93,16 @@ def cpu_baseline(weights, budget_s=30.0):
 from demon_amd.kernel_names import rocprof_kernel_name  # noqa: E402
 
 
+def flush_c_stdio():
+    """fflush(NULL): text that native libraries (RCCL's banner) printed through C stdio must not surface after the JSON line"""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +162,7 @@ def main():
         from demon_amd import distributed as D
         t_bcast, bcast_desc = D.distribute_weights(ctx, host_weights, rank, world,
                                                    route="rccl" if args.weights_bcast == "rccl" else "torch-gpu")
+        flush_c_stdio()
     else:
         ctx.set_weights(host_weights)
 
@@ -312,10 +323,12 @@ def main():
             result["cpu_baseline"] = cpu_baseline(host_weights)
     ctx.close()
     if distributed:
-        dist.barrier()
+        flush_c_stdio()       # RCCL's version banner sits in the C stdio buffer when stdout is a pipe: out with it BEFORE the result,
+        dist.barrier()        # on every rank, so that the JSON line is the last thing this job prints
         dist.destroy_process_group()
+        flush_c_stdio()
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
