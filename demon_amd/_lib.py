@@ -22,7 +22,7 @@ class DemonOutputs(ctypes.Structure):
 
 class LaunchRecord(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 64), ("kernel", ctypes.c_char * 32), ("flops", ctypes.c_double),
-                ("bytes", ctypes.c_double), ("ms", ctypes.c_float)]
+                ("bytes", ctypes.c_double), ("ms", ctypes.c_float), ("reduce_ms", ctypes.c_float)]
 
 
 # every symbol include/demon_hip.h declares: name -> (restype, argtypes)
@@ -40,6 +40,9 @@ SIGNATURES = {
     "demon_comm_destroy": (_I, [_P]),
     "demon_broadcast_weights": (_I, [_P, _P, _I, _I]),
     "demon_weights_slab_bytes": (ctypes.c_int64, [_P]),
+    "demon_weights_slab_layout": (ctypes.c_uint64, [_P]),
+    "demon_comm_count": (_I, [_P, c_int_p]),
+    "demon_copy_weights_from": (_I, [_P, _P]),
     "demon_variant": (_I, [_P]),
     "demon_destroy": (_I, [_P]),
     "demon_last_error": (ctypes.c_char_p, [_P]),

@@ -430,9 +430,13 @@ bool launch_conv_mfma(const ConvArgs &a_in, ConvPlan plan, int nclasses, hipStre
     return a.tickets != nullptr;
 }
 
+thread_local hipEvent_t g_reduce_mark = nullptr;
+thread_local bool g_reduce_marked = false;
+
 void launch_splitk_reduce(const ConvArgs &a, int nclasses, hipStream_t stream)
 {
     const long P = (long)a.N * a.Hp * a.Wp;
+    if (g_reduce_mark && hipEventRecord(g_reduce_mark, stream) == hipSuccess) g_reduce_marked = true;
     if (nclasses == 1 && a.osx == 1 && a.osy == 1 && (a.Wp & 3) == 0 && (a.Wo & 3) == 0 && (a.out_plane & 3) == 0 && (a.out_n_stride & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
         dim3 rgrid((unsigned)((P / 4 + 255) / 256), (unsigned)a.Cout, 1);

@@ -126,6 +126,7 @@ struct demon_ctx {
     int opt_side_branches = 1;
     int opt_fused_pairs = 1;  // conv_pair.hip for the pairs conv_pair_applies() selects
     int opt_fused_inputs = 1;  // one launch for the extra-input assembly of the iterative blocks / the refinement input
+    int opt_tune_fixup = 0;    // demon_autotune also proposes "split-K combined inside the launch" (ksplit + 1000) candidates
     // all packed kernels and biases of the networks live in ONE device slab (alloc_weight_slab), so that
     // demon_broadcast_weights is a single RCCL broadcast of device-resident, already packed data
     float *w_slab = nullptr;
@@ -838,7 +839,9 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
         if ((cands[i].kind == 0 || cands[i].kind == 4 || cands[i].kind == 5) && cands[i].ksplit > 1) split_ms.push_back({ms, i});
     }
     std::sort(split_ms.begin(), split_ms.end());
-    for (size_t q = 0; q < split_ms.size() && q < 6 && !failed; ++q) {
+    // opt-in only (option "tune_in_launch_splitk"): the in-launch form orders its slab stores against the ticket with write-through
+    // stores + s_waitcnt and a relaxed atomic, not with a formal release / acquire pair; no shipped plan uses it
+    for (size_t q = 0; c->opt_tune_fixup && q < split_ms.size() && q < 6 && !failed; ++q) {
         Cand cd = cands[split_ms[q].second];
         cd.ksplit += 1000;
         cands.push_back(cd);
@@ -1432,13 +1435,25 @@ void enqueue_sequence(demon_ctx *c, int kind, int n, int iterations, hipStream_t
 }
 
 // one hipGraph per (sequence, batch, iterations): the whole kernel chain becomes a single launch
+// The arrival counters of the in-launch split-K are zero between launches only as long as every launch runs to its end; after a
+// failed launch (or before a tuning session that may abort candidates) they are put back to zero explicitly.
+void reset_splitk_tickets(demon_ctx *c)
+{
+    for (float *ws : {c->d_ws, c->d_ws_side})
+        if (ws) hipMemsetAsync(ws + kSplitKWorkspaceFloats, 0, sizeof(unsigned) * kSplitKTickets, c->stream);
+}
+
 int run_sequence(demon_ctx *c, int kind, int n, int iterations)
 {
     c->err.clear();
     if (!c->opt_hipgraph) {
         enqueue_sequence(c, kind, n, iterations, c->stream);
-        HIP_TRY(c, hipGetLastError());
-        return c->err.empty() ? DEMON_OK : DEMON_ERR_HIP;
+        if (hipGetLastError() != hipSuccess || !c->err.empty()) {
+            reset_splitk_tickets(c);
+            if (c->err.empty()) c->err = "kernel launch failed";
+            return DEMON_ERR_HIP;
+        }
+        return DEMON_OK;
     }
     char key[64];
     snprintf(key, sizeof key, "%d:%d:%d:%d:%d:%d:%d:%d", kind, n, iterations, c->opt_f2d_method, c->opt_reuse_image, c->opt_side_branches,
@@ -1731,6 +1746,8 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
 };
@@ -1750,8 +1767,11 @@ RcclApi &rccl()
         api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
         api.Broadcast = (decltype(api.Broadcast))dlsym(api.lib, "ncclBroadcast");
+        api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+        api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
         api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Broadcast) api.err = "librccl.so lacks the nccl* entry points";
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Broadcast || !api.AllReduce || !api.CommCount)
+            api.err = "librccl.so lacks the nccl* entry points";
     });
     return api;
 }
@@ -1800,8 +1820,48 @@ int demon_comm_destroy(void *nccl_comm)
     return rc ? rccl_fail(nullptr, "ncclCommDestroy", rc) : DEMON_OK;
 }
 
+int demon_comm_count(void *nccl_comm, int *nranks)
+{
+    RcclApi &r = rccl();
+    if (!nccl_comm || !nranks) return fail(nullptr, DEMON_ERR_INVALID, "null argument");
+    if (!r.err.empty()) return rccl_fail(nullptr, "rccl", 0);
+    int rc = r.CommCount((ncclComm_t)nccl_comm, nranks);
+    return rc ? rccl_fail(nullptr, "ncclCommCount", rc) : DEMON_OK;
+}
+}  // extern "C"
+namespace {
+// Identity of a context's packed weight slab: model variant, image size and, per layer, name, class count, packed rows / columns
+// and the offsets of its kernel and bias inside the slab (FNV-1a).  Two contexts with equal values can exchange slabs byte for byte.
+uint64_t slab_layout_hash(const demon_ctx *c)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](uint64_t v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } };
+    mix((uint64_t)c->variant); mix((uint64_t)c->H); mix((uint64_t)c->W); mix((uint64_t)c->w_slab_floats);
+    for (auto &L : c->layers) {
+        for (char ch : L->name) mix((uint64_t)(unsigned char)ch);
+        mix((uint64_t)L->ncls); mix((uint64_t)L->Krows); mix((uint64_t)L->Mpad);
+        mix((uint64_t)(L->d_wp - c->w_slab)); mix((uint64_t)(L->d_bias - c->w_slab));
+    }
+    return h;
+}
+// What a receiver does once a packed slab has arrived from elsewhere (another rank's broadcast, another context's copy): every
+// variable counts as set -- no demon_set_weight ever ran here -- and the fragment-order copies of the conv_stream / conv_frag
+// layers are stale; captured graphs keep their pointers but are dropped like after any other weight change.
+void slab_arrived(demon_ctx *c)
+{
+    for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+    c->graphs.clear();
+    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; }
+}
+}  // namespace
+extern "C" {
+
+uint64_t demon_weights_slab_layout(const demon_ctx *c) { return c && c->w_slab ? slab_layout_hash(c) : 0; }
+
 // One ncclBroadcast of the packed weight slab (device to device over xGMI; no host staging, no repacking on the receivers:
-// every rank built the same layer table, so the slab layout is identical).  The root must have all weights set.
+// every rank built the same layer table, so the slab layout is identical -- which is CHECKED first: the root's layout hash is
+// broadcast, every rank compares it with its own, and a MIN all-reduce of the verdicts makes all ranks refuse together instead
+// of leaving some of them inside the big collective).  The root must have all weights set.
 int demon_broadcast_weights(demon_ctx *c, void *nccl_comm, int root, int rank)
 {
     if (!c || !nccl_comm) return fail(c, DEMON_ERR_INVALID, "null argument");
@@ -1809,13 +1869,56 @@ int demon_broadcast_weights(demon_ctx *c, void *nccl_comm, int root, int rank)
     RcclApi &r = rccl();
     if (!r.err.empty()) return rccl_fail(c, "rccl", 0);
     std::string missing;
-    if (rank == root && !weights_ready(c, &missing)) return fail(c, DEMON_ERR_NOT_READY, "root rank: weights not set for layer " + missing);
+    const bool root_ready = rank != root || weights_ready(c, &missing);
     hipSetDevice(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    int rc = r.Broadcast(c->w_slab, c->w_slab, c->w_slab_floats, ncclFloat32, root, (ncclComm_t)nccl_comm, c->stream);
+    // header: [layout hash lo, hi, root ready] from the root, then the agreement flag
+    TmpDev tmp;
+    int *hdr = (int *)tmp.alloc(4);
+    if (!hdr) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    const uint64_t mine = slab_layout_hash(c);
+    int h_hdr[4] = {(int)(mine & 0xffffffffu), (int)(mine >> 32), root_ready ? 1 : 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(hdr, h_hdr, sizeof h_hdr, hipMemcpyHostToDevice, c->stream));
+    int rc = r.Broadcast(hdr, hdr, 3, ncclInt32, root, (ncclComm_t)nccl_comm, c->stream);
+    if (rc) return rccl_fail(c, "ncclBroadcast (header)", rc);
+    int got[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(got, hdr, sizeof got, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const bool same = got[0] == h_hdr[0] && got[1] == h_hdr[1];
+    int verdict = (same ? 1 : 0) | (got[2] ? 2 : 0);  // bit 0: my layout equals the root's, bit 1: the root has its weights
+    HIP_TRY(c, hipMemcpyAsync(hdr + 3, &verdict, sizeof verdict, hipMemcpyHostToDevice, c->stream));
+    rc = r.AllReduce(hdr + 3, hdr + 3, 1, ncclInt32, ncclMin, (ncclComm_t)nccl_comm, c->stream);
+    if (rc) return rccl_fail(c, "ncclAllReduce (agreement)", rc);
+    int all = 0;
+    HIP_TRY(c, hipMemcpyAsync(&all, hdr + 3, sizeof all, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!got[2]) return fail(c, DEMON_ERR_NOT_READY, rank == root ? "root rank: weights not set for layer " + missing : std::string("root rank: weights not set"));
+    if (!same) return fail(c, DEMON_ERR_INVALID, "weight slab layout differs from the root's (other model variant, image size or library build)");
+    if ((all & 1) == 0) return fail(c, DEMON_ERR_INVALID, "another rank's weight slab layout differs from the root's: broadcast refused on all ranks");
+    rc = r.Broadcast(c->w_slab, c->w_slab, c->w_slab_floats, ncclFloat32, root, (ncclComm_t)nccl_comm, c->stream);
     if (rc) return rccl_fail(c, "ncclBroadcast", rc);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; }
+    slab_arrived(c);
+    return DEMON_OK;
+}
+
+// The receiver side of demon_broadcast_weights without a second GPU: the packed slab of `src` (same model variant / image size,
+// any device of this process) is copied device to device into `dst`, which then does exactly what a non-root rank does after the
+// collective.  `dst` needs no demon_set_weight call at all.
+int demon_copy_weights_from(demon_ctx *dst, const demon_ctx *src)
+{
+    if (!dst || !src) return fail(dst, DEMON_ERR_INVALID, "null argument");
+    if (!dst->w_slab || !src->w_slab) return fail(dst, DEMON_ERR_INVALID, "context has no networks (demon_create_ops)");
+    if (slab_layout_hash(dst) != slab_layout_hash(src)) return fail(dst, DEMON_ERR_INVALID, "weight slab layouts differ (other model variant or image size)");
+    std::string missing;
+    if (!weights_ready(const_cast<demon_ctx *>(src), &missing)) return fail(dst, DEMON_ERR_NOT_READY, "source context: weights not set for layer " + missing);
+    hipSetDevice(src->device);
+    HIP_TRY(dst, hipStreamSynchronize(src->stream));
+    hipSetDevice(dst->device);
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    HIP_TRY(dst, hipMemcpyPeerAsync(dst->w_slab, dst->device, src->w_slab, src->device, sizeof(float) * dst->w_slab_floats, dst->stream));
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    slab_arrived(dst);
     return DEMON_OK;
 }
 
@@ -1833,6 +1936,7 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
     if (!strcmp(key, "reuse_image_features")) { c->opt_reuse_image = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "fused_pairs")) { c->opt_fused_pairs = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "fused_inputs")) { c->opt_fused_inputs = value ? 1 : 0; return DEMON_OK; }
+    if (!strcmp(key, "tune_in_launch_splitk")) { c->opt_tune_fixup = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "side_branches")) { c->opt_side_branches = (value && c->side_stream && c->d_ws_side != c->d_ws) ? 1 : 0; return DEMON_OK; }
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }
@@ -1888,6 +1992,7 @@ int demon_autotune(demon_ctx *c, int n)
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);  // captured launches embed the old choices
     c->graphs.clear();
     prepare_stream_weights(c);
+    reset_splitk_tickets(c);
     for (auto &L : c->layers) {
         int r = autotune_layer(c, L.get(), n);
         if (r) return fail(c, r, "autotune failed at layer " + L->name);
@@ -2113,23 +2218,29 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
         for (auto &s : c->net_iter) if (active(s)) seq.push_back(&s);
     for (auto &s : c->net_refine) if (active(s)) seq.push_back(&s);
     std::vector<std::string> tags(seq.size());
-    std::vector<hipEvent_t> ev(2 * seq.size());
+    std::vector<hipEvent_t> ev(3 * seq.size());  // per step: start, in front of the split-K reduce launch (if any), end
     for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
-    std::vector<double> ms(seq.size(), 0.0);
+    std::vector<double> ms(seq.size(), 0.0), red_ms(seq.size(), 0.0);
+    std::vector<char> marked(seq.size(), 0);
     for (int rep = 0; rep < repeats + 1; ++rep) {  // first pass = warm-up
         for (size_t i = 0; i < seq.size(); ++i) {
-            HIP_TRY(c, hipEventRecord(ev[2 * i], c->stream));
+            HIP_TRY(c, hipEventRecord(ev[3 * i], c->stream));
             g_last_kernel = nullptr;
+            g_reduce_mark = ev[3 * i + 1];
+            g_reduce_marked = false;
             seq[i]->fn(n, c->stream);
+            g_reduce_mark = nullptr;
+            marked[i] = g_reduce_marked ? 1 : 0;
             tags[i] = g_last_kernel ? g_last_kernel : "";
-            HIP_TRY(c, hipEventRecord(ev[2 * i + 1], c->stream));
+            HIP_TRY(c, hipEventRecord(ev[3 * i + 2], c->stream));
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (rep == 0) continue;
         for (size_t i = 0; i < seq.size(); ++i) {
             float t = 0;
-            HIP_TRY(c, hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+            HIP_TRY(c, hipEventElapsedTime(&t, ev[3 * i], ev[3 * i + 2]));
             ms[i] += t;
+            if (marked[i] && hipEventElapsedTime(&t, ev[3 * i + 1], ev[3 * i + 2]) == hipSuccess) red_ms[i] += t;
         }
     }
     for (auto &e : ev) hipEventDestroy(e);
@@ -2141,6 +2252,7 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
         rec[i].flops = seq[i]->flops_per_sample * n;
         rec[i].bytes = seq[i]->bytes_per_sample * n + seq[i]->bytes_fixed;
         rec[i].ms = (float)(ms[i] / repeats);
+        rec[i].reduce_ms = (float)(red_ms[i] / repeats);
     }
     return DEMON_OK;
 }
@@ -2226,10 +2338,10 @@ int demon_op_scale_invariant_gradient(demon_ctx *c, float *out, const float *in,
     if (!out || !in || !deltas || !weights || nc < 1 || h < 1 || w < 1 || ndeltas < 1 || ndeltas > 8)
         return fail(c, DEMON_ERR_INVALID, "bad argument (1..8 deltas)");
     const size_t hw = (size_t)h * w;
-    float *d_in = tmp.upload(in, nc * hw), *d_out = tmp.alloc(2 * ndeltas * nc * hw);
+    float *d_in = tmp.upload(in, nc * hw), *d_out = tmp.alloc(2 * nc * hw);
     if (!d_in || !d_out) return fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
     launch_sig(d_out, d_in, nc, h, w, deltas, weights, ndeltas, epsilon, c->stream);
-    OP_FINISH(c, d_out, out, 2 * ndeltas * nc * hw);
+    OP_FINISH(c, d_out, out, 2 * nc * hw);
 }
 
 int demon_op_depth_to_normals(demon_ctx *c, float *out, const float *depth, const float *intrinsics, int n, int h, int w,

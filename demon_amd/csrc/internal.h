@@ -193,6 +193,10 @@ int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);
 
 void launch_splitk_reduce(const ConvArgs &a, int nclasses, hipStream_t stream);
+// demon_profile_full: when set, launch_splitk_reduce records this event on the stream in front of the reduce kernel (and sets the
+// flag), so that a layer's own kernel and the reduce launch that follows it are timed separately
+extern thread_local hipEvent_t g_reduce_mark;
+extern thread_local bool g_reduce_marked;
 
 // ---- register-streaming contraction for the deep small-map layers (conv_stream.hip) -----------------------------------------
 struct StreamArgs {

@@ -425,21 +425,22 @@ __global__ __launch_bounds__(256) void sig_kernel(float *__restrict__ out, const
     if (x >= W || y >= H) return;
     auto at = [&](int yy, int xx) { return staged ? tile[(yy - ty0 + halo) * tw + (xx - tx0 + halo)] : p[yy * W + xx]; };
     const float u = at(y, x);
-    // channel = (z * ndeltas + k) * 2 + {x, y}: one gradient pair per delta (v2/losses.py:76-79 concatenates one-delta calls)
+    // lmbspecialops contract: channels fold into the batch ([N,C,H,W] -> [N*C,2,H,W]) and the deltas are SUMMED with their weights;
+    // that is why v2/losses.py:76-79 calls the op once per delta and concatenates the results itself
+    float gx = 0.0f, gy = 0.0f;
     for (int k = 0; k < sp.n; ++k) {
         const int d = sp.deltas[k];
-        float gx = 0.0f, gy = 0.0f;
         if (x + d >= 0 && x + d < W) {
             const float un = at(y, x + d);
-            gx = sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
+            gx += sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
         }
         if (y + d >= 0 && y + d < H) {
             const float un = at(y + d, x);
-            gy = sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
+            gy += sp.weights[k] * (un - u) / (fabsf(un) + fabsf(u) + eps);
         }
-        out[(((long)z * sp.n + k) * 2 + 0) * H * W + y * W + x] = gx;
-        out[(((long)z * sp.n + k) * 2 + 1) * H * W + y * W + x] = gy;
     }
+    out[((long)z * 2 + 0) * H * W + y * W + x] = gx;
+    out[((long)z * 2 + 1) * H * W + y * W + x] = gy;
 }
 
 // Median keys: a monotone map of float bits to unsigned (negative values reversed, sign bit flipped) with every NaN mapped

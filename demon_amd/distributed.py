@@ -31,22 +31,40 @@ def torch_exchange(payload, src=0):
 
 class NativeComm:
     """RCCL communicator owned through the C ABI (include/demon_hip.h: demon_comm_*).  `exchange(bytes_or_None) -> bytes`
-    ships rank 0's unique id to everybody (default: torch.distributed)."""
+    ships rank 0's unique id to everybody (default: torch.distributed).
+
+    The id exchange is UNCONDITIONAL: rank 0 always ships something -- the 128-byte id, or a marker `b"!" + reason` when it could
+    not create one (librccl not loadable, ncclGetUniqueId failed) -- so the other ranks, who are blocked in `exchange`, never wait
+    for a rank 0 that has already given up; every rank then raises the same error and can fall back together."""
 
     def __init__(self, rank, world, device, exchange=torch_exchange):
         from . import _lib
         self.lib = _lib.load()
         self.rank, self.world, self.device = rank, world, device
-        buf = ctypes.create_string_buffer(128)
+        self.handle = None
+        payload = None
         if rank == 0:
-            self._check(self.lib.demon_comm_get_unique_id(buf), "demon_comm_get_unique_id")
-        uid = exchange(buf.raw if rank == 0 else None) if world > 1 else buf.raw
-        self.handle = ctypes.c_void_p()
-        self._check(self.lib.demon_comm_init_rank(ctypes.byref(self.handle), world, uid, rank, device), "demon_comm_init_rank")
+            buf = ctypes.create_string_buffer(128)
+            rc = self.lib.demon_comm_get_unique_id(buf)
+            payload = buf.raw if rc == 0 else b"!demon_comm_get_unique_id failed (%d): %s" % (rc, self.lib.demon_last_error(None))
+            if rc != 0 and len(payload) == 128:
+                payload += b" "   # an id is exactly 128 bytes, the marker never is
+        uid = exchange(payload) if world > 1 else payload
+        if uid[:1] == b"!" and len(uid) != 128:
+            raise RuntimeError("rank 0 could not create an RCCL id: " + uid[1:].decode(errors="replace"))
+        handle = ctypes.c_void_p()
+        self._check(self.lib.demon_comm_init_rank(ctypes.byref(handle), world, uid, rank, device), "demon_comm_init_rank")
+        self.handle = handle
 
     def _check(self, rc, what):
         if rc != 0:
             raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.demon_last_error(None).decode()))
+
+    def count(self):
+        """ncclCommCount: the number of ranks RCCL itself reports for this communicator"""
+        n = ctypes.c_int(0)
+        self._check(self.lib.demon_comm_count(self.handle, ctypes.byref(n)), "demon_comm_count")
+        return int(n.value)
 
     def broadcast_weights(self, ctx, root=0):
         """one ncclBroadcast of ctx's packed weight slab from `root`; every rank must call it"""
@@ -58,6 +76,20 @@ class NativeComm:
         if getattr(self, "handle", None):
             self.lib.demon_comm_destroy(self.handle)
             self.handle = None
+
+
+def all_ranks_ok(ok, device_index=None):
+    """MIN over the ranks of a 0 / 1 flag through the initialised torch.distributed group; the flag tensor lives where the
+    group's backend can reduce it (CPU for gloo, this rank's GPU for nccl = RCCL)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(ok)
+    backend = str(dist.get_backend()).lower()
+    dev = torch.device("cuda", device_index if device_index is not None else torch.cuda.current_device()) if "nccl" in backend else torch.device("cpu")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
 
 
 def broadcast_blob(blob, nfloats, device, src=0):
@@ -77,32 +109,33 @@ def broadcast_blob(blob, nfloats, device, src=0):
     return torch.from_numpy(np.ascontiguousarray(blob, np.float32)).to(device)
 
 
+LAST_BROADCAST = {}   # what the most recent distribute_weights call did on this rank: route, rccl_nranks, seconds (bench.py prints it)
+
+
 def distribute_weights(ctx, host_weights, rank, world, route="rccl", comm=None):
     """Puts rank 0's weights (dict tf name -> array; None on the other ranks) on every rank's context.
     Returns (seconds spent in the broadcast, route description)."""
     import time
     from . import weights as W
+    LAST_BROADCAST.clear()
+    LAST_BROADCAST.update(route=route, rccl_nranks=None, seconds=0.0)
     if route == "rccl":
         own = comm is None
         note = ""
         if own:
-            # every rank must end up on the same route: agree on whether the communicator came up everywhere
+            # every rank must end up on the same route.  NativeComm's id exchange is unconditional (rank 0 ships an error marker
+            # instead of an id when it has none), so all ranks reach the agreement below having run the same collectives
             try:
                 comm = NativeComm(rank, world, ctx.device)
                 ok = 1
-            except Exception as e:   # librccl missing, id exchange or ncclCommInitRank failed
+            except Exception as e:   # librccl missing, rank 0 without an id, or ncclCommInitRank failed
                 comm, ok, note = None, 0, " (native RCCL init failed on rank %d: %s)" % (rank, e)
-            if world > 1:
-                import torch
-                import torch.distributed as dist
-                flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", ctx.device))
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if not ok:
+            if not all_ranks_ok(ok, ctx.device):
                 if comm is not None:
                     comm.close()
                 dt, desc = distribute_weights(ctx, host_weights, rank, world, route="torch-gpu")
                 return dt, desc + " [fallback]" + note
+        nranks = comm.count()
         if rank == 0:
             ctx.set_weights(host_weights)      # TF layouts -> packed slab, on the root only
         t0 = time.perf_counter()
@@ -110,8 +143,9 @@ def distribute_weights(ctx, host_weights, rank, world, route="rccl", comm=None):
         dt = time.perf_counter() - t0
         if own:
             comm.close()
-        return dt, "one ncclBroadcast of the packed %.0f MB weight slab through the C ABI (demon_broadcast_weights)" % (
-            ctx.lib.demon_weights_slab_bytes(ctx.h) / 1e6)
+        LAST_BROADCAST.update(rccl_nranks=nranks, seconds=dt)
+        return dt, "one ncclBroadcast of the packed %.0f MB weight slab through the C ABI (demon_broadcast_weights, %d RCCL ranks)" % (
+            ctx.lib.demon_weights_slab_bytes(ctx.h) / 1e6, nranks)
     import torch
     order = ctx.variables()
     blob = W.weights_to_blob(host_weights, order) if rank == 0 else None
@@ -125,6 +159,7 @@ def distribute_weights(ctx, host_weights, rank, world, route="rccl", comm=None):
         ctx.set_weights_blob_device(t.data_ptr(), t.numel())
     else:
         ctx.set_weights_blob(t.numpy())
+    LAST_BROADCAST.update(route=route, seconds=dt)
     return dt, "torch.distributed.broadcast of the %.0f MB TF-layout blob (%s)" % (4e-6 * ctx.blob_size(), route)
 
 

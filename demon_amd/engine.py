@@ -103,6 +103,13 @@ class DemonContext:
     def set_weights_blob_device(self, device_ptr, nfloats):
         self._check(self.lib.demon_set_weights_blob_device(self.h, ctypes.c_void_p(device_ptr), nfloats))
 
+    def copy_weights_from(self, src):
+        """demon_copy_weights_from: the packed weight slab of `src` device to device, then the epilogue of a broadcast receiver"""
+        self._check(self.lib.demon_copy_weights_from(self.h, src.h))
+
+    def slab_layout(self):
+        return int(self.lib.demon_weights_slab_layout(self.h))
+
     def autotune(self, n):
         """measure every kernel variant per layer at batch n and keep the fastest (launch plans only)"""
         self._check(self.lib.demon_autotune(self.h, int(n)))
@@ -245,8 +252,8 @@ class DemonContext:
         rec = (LaunchRecord * cap)()
         cnt = ctypes.c_int()
         self._check(self.lib.demon_profile_full(self.h, n, iterations, repeats, rec, cap, ctypes.byref(cnt)))
-        return [{"name": r.name.decode(), "kernel": r.kernel.decode(), "flops": r.flops, "bytes": r.bytes, "ms": r.ms}
-                for r in rec[:min(cnt.value, cap)]]
+        return [{"name": r.name.decode(), "kernel": r.kernel.decode(), "flops": r.flops, "bytes": r.bytes, "ms": r.ms,
+                 "reduce_ms": r.reduce_ms} for r in rec[:min(cnt.value, cap)]]
 
     # ---- lmbspecialops-level ops --------------------------------------------------------------------------
     def depth_to_flow(self, depth, intrinsics, rotation, translation, inverse_depth=False, normalize_flow=False,
@@ -295,20 +302,24 @@ class DemonContext:
         return out
 
     def scale_invariant_gradient(self, x, deltas=(1,), weights=(1.0,), epsilon=0.001):
-        """[N,C,H,W] -> [N, C*2*len(deltas), H, W], channel (c*len(deltas) + k)*2 + {0: x, 1: y} (one delta and C = 1: the
-        [N,2,H,W] tensor the reference concatenates and slices in pairs, v2/losses.py:76-79, :99-102)"""
+        """lmbspecialops contract: [N,C,H,W] -> [N*C, 2, H, W] (channels fold into the batch; channel 0 = x, 1 = y) and the
+        deltas of one call are SUMMED with their weights -- which is why the reference calls the op once per delta and
+        concatenates on axis 1 itself (v2/losses.py:76-79) before slicing (x, y) pairs (:99-102)"""
         x = _f32(x)
         n, c, h, w = x.shape
         d = np.ascontiguousarray(deltas, np.int32)
         wt = _f32(weights, (len(d),), "weights")
-        out = np.empty((n, c * 2 * len(d), h, w), np.float32)
+        out = np.empty((n * c, 2, h, w), np.float32)
         self._check(self.lib.demon_op_scale_invariant_gradient(
             self.h, _fp(out), _fp(x), n * c, h, w, d.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(wt), len(d),
             float(epsilon)))
         return out
 
     def depth_to_normals(self, depth, intrinsics, inverse_depth=False):
-        """v2/losses.py:336-337: [N,1,H,W] depth -> [N,3,H,W] camera-frame normals (NaN at the border / invalid depth)"""
+        """v2/losses.py:336-337: [N,1,H,W] depth -> [N,3,H,W] camera-frame normals (NaN at the border / invalid depth).
+        UNVERIFIED against lmbspecialops (its source is not in the reference tree): pixel centres at +0.5, one-sided differences
+        with the smaller depth change per axis and a normal that points towards the camera are decisions of this library, held
+        only by analytic plane tests (tests/test_pins.py) -- normal0 / normal2 ground truth may differ from the reference's."""
         depth = _f32(depth)
         n, c, h, w = depth.shape
         if c != 1:

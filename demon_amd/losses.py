@@ -25,7 +25,8 @@ def pointwise_l2_loss(inp, gt, epsilon, data_format="NCHW"):
 
 
 def scale_invariant_gradient(inp, deltas, weights, epsilon=0.001):
-    """v2/losses.py:57-79: one op call per delta, concatenated on axis 1"""
+    """v2/losses.py:57-79: one op call per delta, concatenated on axis 1.  The op folds channels into the batch, so
+    [N,C,H,W] -> [N*C, 2*len(deltas), H, W] (flow2: [2N,10,H,W], as in the reference)"""
     assert len(deltas) == len(weights)
     return np.concatenate([sops.scale_invariant_gradient(inp, deltas=[d], weights=[w], epsilon=epsilon)
                            for d, w in zip(deltas, weights)], axis=1)

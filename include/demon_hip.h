@@ -91,7 +91,10 @@ int demon_set_weights_blob_device(demon_ctx *ctx, const void *device_blob, int64
  * "side_branches" 0/1 (default 1): the motion head and the level-5 flow head run on a second HIP stream next to the decoder
  * they do not depend on (fork / join by events, captured into the same hipGraph) -- same kernels, same results;
  * "fused_pairs" 0/1 (default 1): the first k x 1 / 1 x k pair (conv1, 6 input channels, the largest intermediate) as one launch,
- * the intermediate staying in LDS (conv_pair.hip) -- same arithmetic, other summation order */
+ * the intermediate staying in LDS (conv_pair.hip) -- same arithmetic, other summation order;
+ * "fused_inputs" 0/1 (default 1): the extra-input assembly of the iterative blocks / the refinement input as one launch each;
+ * "tune_in_launch_splitk" 0/1 (default 0): demon_autotune may also select "split-K combined inside the launch" (experimental:
+ * ordered by write-through stores + a relaxed ticket, not by a formal release / acquire pair; no shipped plan uses it) */
 int demon_set_option(demon_ctx *ctx, const char *key, int value);
 /* Times every applicable kernel variant (im2col / patch-staged, tile shape, split-K) of every layer at batch n on
  * this GPU and keeps the fastest per layer (~1 s; results do not change, only launch plans). */
@@ -148,7 +151,8 @@ typedef struct demon_launch_record {
                           reduce), "conv_patch<64x128,t5>", "deconv4<32x128>", "conv_pair", "conv_small", "warp2d", ... */
     double flops;      /* algorithmic 2*MAC of this launch (0 for non conv ops) */
     double bytes;      /* algorithmic bytes read + written */
-    float ms;
+    float ms;          /* whole step, including the split-K reduce launch where one follows */
+    float reduce_ms;   /* of which: the conv_splitk_reduce launch (0 when the step has none) -- ms - reduce_ms is the kernel alone */
 } demon_launch_record;
 int demon_profile_full(demon_ctx *ctx, int n, int iterations, int repeats, demon_launch_record *records, int cap,
                        int *count);
@@ -166,9 +170,12 @@ int demon_debug_timeline(demon_ctx *ctx, const char *layer_name, int n, uint64_t
  *   warp2d                   blocks_original.py:171-176, :336   (border_mode 0 clamp, 1 value)
  *   leaky_relu               helpers.py:60-63
  *   replace_nonfinite        v2/losses.py:49
- *   scale_invariant_gradient v2/losses.py:76-79   out [nc * ndeltas * 2, h, w]: channel (z*ndeltas + k)*2 + {x, y}
+ *   scale_invariant_gradient v2/losses.py:76-79   out [nc, 2, h, w] (channels fold into the batch; 0 = x, 1 = y), the deltas of one
+ *                            call are summed with their weights (lmbspecialops contract; the reference concatenates one-delta calls)
  *   median3x3_downsample     examples/evaluation.py:173, v2/helpers.py:102   (NaN sorts last)
- *   depth_to_normals         v2/losses.py:336-337   out [n, 3, h, w], NaN at the border / invalid depth   */
+ *   depth_to_normals         v2/losses.py:336-337   out [n, 3, h, w], NaN at the border / invalid depth.  UNVERIFIED against
+ *                            lmbspecialops (source absent): pixel centres +0.5, one-sided differences with the smaller depth change,
+ *                            normal towards the camera are this library's decisions; pinned only by analytic plane tests   */
 int demon_op_depth_to_flow(demon_ctx *ctx, float *out, const float *depth, const float *intrinsics,
                            const float *rotation, const float *translation, int n, int h, int w,
                            int inverse_depth, int normalize_flow, int gate);
@@ -198,6 +205,13 @@ int demon_op_pointwise_l2_loss(demon_ctx *ctx, float *loss, const float *inp, co
  *   demon_broadcast_weights  : ONE ncclBroadcast (float32) of the packed device-resident weight slab from `root` on the
  *                              context's stream, then marks every variable as set; `nccl_comm` may be any ncclComm_t whose
  *                              rank `rank` is this process.  Collective: every rank of the communicator must call it.
+ *                              The collective is preceded by a 12-byte header broadcast + a 4-byte MIN all-reduce: the root's
+ *                              slab layout (demon_weights_slab_layout) must equal every rank's, else ALL ranks return
+ *                              DEMON_ERR_INVALID without entering the big broadcast.
+ *   demon_comm_count         : ncclCommCount -- how many ranks the communicator really has (bench.py prints it)
+ *   demon_copy_weights_from  : the receiver side without a second GPU / process: device-to-device copy of `src`'s packed
+ *                              slab into `dst` (same layout), then exactly the epilogue of a non-root rank of
+ *                              demon_broadcast_weights.  `dst` needs no demon_set_weight call.
  * librccl.so is dlopen'ed on first use; without it these return DEMON_ERR_HIP and nothing else is affected. */
 #define DEMON_COMM_ID_BYTES 128
 int demon_comm_get_unique_id(char *id /* [DEMON_COMM_ID_BYTES] */);
@@ -205,6 +219,9 @@ int demon_comm_init_rank(void **nccl_comm, int nranks, const char *id /* [DEMON_
 int demon_comm_destroy(void *nccl_comm);
 int demon_broadcast_weights(demon_ctx *ctx, void *nccl_comm, int root, int rank);
 int64_t demon_weights_slab_bytes(const demon_ctx *ctx);
+uint64_t demon_weights_slab_layout(const demon_ctx *ctx);  /* hash of model variant, image size and the per-layer slab offsets; 0: no networks */
+int demon_comm_count(void *nccl_comm, int *nranks);
+int demon_copy_weights_from(demon_ctx *dst, const demon_ctx *src);
 
 /* ---- layer-level entry points (host buffers; TF weight layouts) -------------------------------------
  * Replace the tf.layers calls of helpers.py:85-94 / :128-153 (conv2d on a zero padded input),

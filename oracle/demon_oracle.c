@@ -28,7 +28,7 @@
  *     (tests/golden/make_golden_inputs.py, tests/test_preprocess.py) -- host code, listed for completeness.
  * Still unpinned (no in-tree material constrains them; each function states the rule it implements):
  *   warp2d's treatment of taps outside the image and of non-finite displacements, flow_to_depth on geometrically
- *   inconsistent flow (DLT vs closed form), scale_invariant_gradient (border rule, layout for C > 1), median3x3_downsample
+ *   inconsistent flow (DLT vs closed form), scale_invariant_gradient (border rule), median3x3_downsample
  *   (NaN ordering: "NaN sorts last" here), depth_to_normals (difference scheme, orientation), and every TensorFlow layer
  *   (conv2d 'valid' on a padded input, conv2d_transpose, dense, 'same' padding of the v2 model; checked against PyTorch and
  *   naive loops only): they restate published semantics at the reference's call sites, which each function cites.
@@ -276,11 +276,12 @@ void ref_replace_nonfinite(float *out, const float *in, size_t count, float valu
 
 /* ---------------------------------------------------------------------------------------------
  * sops.scale_invariant_gradient -- v2/losses.py:76-79 (one delta per call there, results concatenated
- * on axis 1; slices of two channels are compared by scale_invariant_gradient_loss :82-104).
- * in [N,C,H,W] -> out [N, C*2*ndeltas, H, W], channel = (c*ndeltas + k)*2 + {0: x, 1: y}:
- *   gx_k = w_k*(u(x+d_k,y)-u(x,y))/(|u(x+d_k,y)|+|u(x,y)|+eps), zero where the neighbour is outside
- *   the image; gy_k alike.  For one delta and C = 1 this is the [N,2,H,W] tensor of the call site.
- * Unpinned (lmbspecialops absent): the layout for C > 1 / several deltas, the border rule.
+ * on axis 1 by the caller; slices of two channels are compared by scale_invariant_gradient_loss :82-104).
+ * The op does not distinguish channels from batch: in [N,C,H,W] -> out [N*C, 2, H, W], channel 0 = x, 1 = y,
+ * and the deltas of ONE call are summed with their weights (lmbspecialops documentation):
+ *   gx = sum_k w_k*(u(x+d_k,y)-u(x,y))/(|u(x+d_k,y)|+|u(x,y)|+eps), a term is zero where the neighbour is
+ *   outside the image; gy alike.
+ * Unpinned (lmbspecialops source absent): the border rule.
  * ------------------------------------------------------------------------------------------- */
 void ref_scale_invariant_gradient(float *out, const float *in, int NC, int H, int W, const int *deltas,
                                   const float *weights, int ndeltas, float epsilon)
@@ -290,20 +291,20 @@ void ref_scale_invariant_gradient(float *out, const float *in, int NC, int H, in
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
                 const float u = in[(size_t)z * hw + y * W + x];
+                float gx = 0, gy = 0;
                 for (int k = 0; k < ndeltas; ++k) {
                     const int d = deltas[k];
-                    float gx = 0, gy = 0;
                     if (x + d >= 0 && x + d < W) {
                         const float un = in[(size_t)z * hw + y * W + x + d];
-                        gx = weights[k] * (un - u) / (fabsf(un) + fabsf(u) + epsilon);
+                        gx += weights[k] * (un - u) / (fabsf(un) + fabsf(u) + epsilon);
                     }
                     if (y + d >= 0 && y + d < H) {
                         const float un = in[(size_t)z * hw + (y + d) * W + x];
-                        gy = weights[k] * (un - u) / (fabsf(un) + fabsf(u) + epsilon);
+                        gy += weights[k] * (un - u) / (fabsf(un) + fabsf(u) + epsilon);
                     }
-                    out[(((size_t)z * ndeltas + k) * 2 + 0) * hw + y * W + x] = gx;
-                    out[(((size_t)z * ndeltas + k) * 2 + 1) * hw + y * W + x] = gy;
                 }
+                out[((size_t)z * 2 + 0) * hw + y * W + x] = gx;
+                out[((size_t)z * 2 + 1) * hw + y * W + x] = gy;
             }
 }
 

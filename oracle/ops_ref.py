@@ -97,7 +97,7 @@ def scale_invariant_gradient(x, deltas=(1,), weights=(1.0,), epsilon=0.001):
     N, C, H, W = x.shape
     d = np.ascontiguousarray(deltas, np.int32)
     w, pw = _f(weights)
-    out = np.empty((N, C * 2 * len(d), H, W), np.float32)
+    out = np.empty((N * C, 2, H, W), np.float32)   # channels fold into the batch, deltas are summed (lmbspecialops contract)
     lib().ref_scale_invariant_gradient(out.ctypes.data_as(_f32p), px, N * C, H, W, d.ctypes.data_as(_i32p), pw,
                                        len(d), ctypes.c_float(epsilon))
     return out

@@ -77,6 +77,54 @@ def test_two_process_broadcast_and_sharding(tmp_path):
         assert np.abs(got - want[k]).sum() / np.abs(want[k]).sum() < 1e-5
 
 
+def _consensus_worker(rank, world, port, tmpdir):
+    """the 'rccl' route's bring-up on a box where rank 0 cannot create an RCCL id (no GPU here: ncclGetUniqueId fails): the id
+    exchange must still run on every rank (rank 0 ships an error marker), every rank must raise, and the MIN all-reduce of the
+    verdicts must work on the gloo group (CPU flag tensor) -- nobody may hang in a collective the others never enter"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from demon_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from demon_amd import _lib
+        try:                               # natural course on this box (the id may or may not come up; ncclCommInitRank cannot)
+            D.NativeComm(rank, world, 0)
+            natural = 1
+        except RuntimeError:
+            natural = 0
+        assert D.all_ranks_ok(natural) is False
+        if rank == 0:                      # now the advisor's case for certain: rank 0 fails BEFORE the id exchange
+            _lib.load().demon_comm_get_unique_id = lambda buf: -2
+        try:
+            D.NativeComm(rank, world, 0)
+            ok, msg = 1, ""
+        except RuntimeError as e:
+            ok, msg = 0, str(e)
+        agreed = D.all_ranks_ok(ok)
+        # a second, healthy-looking rank must be overruled by the failed one
+        mixed = D.all_ranks_ok(rank != 0)
+        with open(os.path.join(tmpdir, "consensus%d.txt" % rank), "w") as f:
+            f.write("%d|%d|%d|%s" % (ok, int(agreed), int(mixed), msg))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_bringup_failure_reaches_consensus_without_hanging(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.is_available():
+        pytest.skip("needs a box where ncclGetUniqueId fails (no GPU)")
+    port = _free_port()
+    mp.spawn(_consensus_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = (tmp_path / "consensus0.txt").read_text().split("|", 3)
+    r1 = (tmp_path / "consensus1.txt").read_text().split("|", 3)
+    assert r0[:3] == ["0", "0", "0"] and r1[:3] == ["0", "0", "0"]
+    assert "rank 0 could not create an RCCL id" in r0[3] and "demon_comm_get_unique_id failed (-2)" in r0[3]
+    assert "rank 0 could not create an RCCL id" in r1[3]      # rank 1 learnt it through the exchange, not by timing out
+
+
 # ---- GPU: the real contexts behind the N > 1 path, as far as one GPU allows ---------------------------------------------
 def _gpu_worker(rank, world, port, tmpdir):
     """two ranks SHARING GPU 0 (RCCL refuses two ranks on one device, so the collective runs over gloo; everything else is
@@ -154,3 +202,59 @@ def test_rccl_broadcast_through_the_c_abi_single_rank():
     finally:
         comm.close()
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_weight_slab_receiver_path_without_set_weight():
+    """The NON-ROOT side of demon_broadcast_weights (demon_api.hip: slab arrives, every variable counts as set, fragment-order
+    copies refreshed) exercised with one GPU: demon_copy_weights_from moves rank-0-style packed data device to device into a
+    context that never saw demon_set_weight, which must then produce bit-identical outputs -- with a launch plan that uses the
+    conv_stream / conv_frag layers (fragment-order weights) and through hipGraph replay."""
+    from demon_amd import DemonContext, DemonError, weights as W
+    from conftest import make_inputs
+    n = 2
+    pair, img2_2 = make_inputs(n, seed=79)
+    src = DemonContext(0, n, 192, 256)
+    dst = DemonContext(0, n, 192, 256)
+    other = DemonContext(0, n, 224, 256)       # another image size -> another slab layout (motion_fc1 depends on it)
+    try:
+        with pytest.raises(DemonError, match="weights not set"):
+            dst.bootstrap(pair, img2_2)
+        with pytest.raises(DemonError, match="source context: weights not set"):
+            dst.copy_weights_from(src)
+        src.set_weights(W.synthetic_weights(seed=1))
+        assert src.slab_layout() == dst.slab_layout() != 0
+        assert other.slab_layout() != src.slab_layout()
+        with pytest.raises(DemonError, match="layouts differ"):
+            other.copy_weights_from(src)
+        for c in (src, dst):
+            assert c.load_tuned_plan(n) in (1, 8)   # nearest shipped plan: streaming / fragment-tiled kernels on the deep layers
+        want = src.full(pair, img2_2, iterations=2)
+        dst.copy_weights_from(src)
+        got = dst.full(pair, img2_2, iterations=2)
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k])
+        assert any(r["kernel"].startswith(("conv_frag", "conv_stream")) for r in dst.profile_full(n, 1, 1))
+        # weights change on the source, arrive again: the receiver must drop its graphs / fragment copies and follow
+        w2 = W.synthetic_weights(seed=2)
+        src.set_weights(w2)
+        dst.copy_weights_from(src)
+        want2 = src.full(pair, img2_2, iterations=2)
+        got2 = dst.full(pair, img2_2, iterations=2)
+        for k in want2:
+            np.testing.assert_array_equal(got2[k], want2[k])
+        assert np.abs(got2["predict_depth0"] - got["predict_depth0"]).max() > 0
+    finally:
+        src.close()
+        dst.close()
+        other.close()
+
+
+@pytest.mark.gpu
+def test_comm_count_reports_the_rccl_world():
+    from demon_amd import distributed as D
+    comm = D.NativeComm(0, 1, 0)
+    try:
+        assert comm.count() == 1
+    finally:
+        comm.close()

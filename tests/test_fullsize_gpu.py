@@ -6,7 +6,7 @@ size-independent properties of the path, plus the oracle on a sample of the batc
     in a small batch on another context (other launch plans -> summation order only);
   * permutation equivariance: permuting the pairs permutes the outputs, bit for bit;
   * determinism: two runs are bit-identical;
-  * the oracle agrees on sampled pairs of the big batch (relative L1 <= 1e-3);
+  * the oracle agrees on sampled pairs of the big batch (8 of 32 at configs[2], 1 of 64 at configs[4]; relative L1 <= 1e-3);
   * depth -> flow -> depth round trip through the two geometry kernels at full batch and resolution.
 """
 import numpy as np
@@ -43,12 +43,15 @@ def test_config2_batch32_full_pipeline(gpu_ctx, synth_weights):
         small = gpu_ctx.full(pair[:4], img2_2[:4], iterations=3)
         for k in KEYS:
             assert rel_l1(got[k][:4], small[k]) < 1e-4, k
-        # the oracle on two pairs of the batch
-        sel = [5, 31]
-        want = net_ref.DemonRef(synth_weights).full(pair[sel], img2_2[sel], iterations=3)
-        for k in KEYS:
-            err = rel_l1(got[k][sel], want[k])
-            assert err < 1e-3, "%s rel L1 %.3e" % (k, err)
+        # the oracle on eight pairs of the batch (two chunks of four: the CPU restatement stays within seconds)
+        ref = net_ref.DemonRef(synth_weights)
+        for sel in ([0, 5, 9, 14], [18, 23, 27, 31]):
+            want = ref.full(pair[sel], img2_2[sel], iterations=3)
+            for k in KEYS:
+                err = rel_l1(got[k][sel], want[k])
+                assert err < 1e-3, "%s rel L1 %.3e" % (k, err)
+                for j, i in enumerate(sel):
+                    assert rel_l1(got[k][i], want[k][j]) < 1e-3, (k, i)
     finally:
         ctx.close()
 

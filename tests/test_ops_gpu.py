@@ -115,15 +115,16 @@ def test_elementwise_and_stencils(gpu_ctx):
     for deltas, weights in (([1], [1.0]), ([2], [0.5]), ([1, 2, 4, 8, 16], [1, 0.5, 0.25, 0.125, 0.0625])):
         got = gpu_ctx.scale_invariant_gradient(u, deltas, weights, 0.01)
         want = ops_ref.scale_invariant_gradient(u, deltas, weights, 0.01)
-        assert got.shape == want.shape == (2, 3 * 2 * len(deltas), 48, 64)   # channel (c*nd + k)*2 + {x, y}
+        assert got.shape == want.shape == (2 * 3, 2, 48, 64)   # channels fold into the batch, deltas are summed
         assert np.abs(got - want).max() < 1e-5
-    # C = 2 (the flow case, v2/losses.py:343), one delta per call as the reference does (:76-79): pairs the loss slices (:99-102)
+    # C = 2 (the flow case, v2/losses.py:343), one delta per call as the reference does (:76-79)
     f = rng.standard_normal((3, 2, 48, 64)).astype(np.float32)
     for d in (1, 2, 4, 8, 16):
         got = gpu_ctx.scale_invariant_gradient(f, [d], [1.0], 0.001)
-        assert got.shape == (3, 4, 48, 64)
-        for c in range(2):
-            np.testing.assert_allclose(got[:, 2 * c:2 * c + 2], ops_ref.scale_invariant_gradient(f[:, c:c + 1], [d], [1.0], 0.001), atol=1e-5)
+        assert got.shape == (6, 2, 48, 64)
+        for b in range(3):
+            for c in range(2):
+                np.testing.assert_allclose(got[b * 2 + c], ops_ref.scale_invariant_gradient(f[b:b + 1, c:c + 1], [d], [1.0], 0.001)[0], atol=1e-5)
     for shape in ((2, 3, 192, 256), (1, 1, 7, 9)):
         x = rng.standard_normal(shape).astype(np.float32)
         np.testing.assert_array_equal(gpu_ctx.median3x3_downsample(x), ops_ref.median3x3_downsample(x))
@@ -268,7 +269,17 @@ def test_ground_truth_preparation_mirror(gpu_ctx):
     want = np.concatenate([ops_ref.scale_invariant_gradient(pyr[2], [d], [1.0], 0.001) for d in deltas], axis=1)
     assert gt["depth2_sig"].shape == (n, 10, 48, 64)
     close(gt["depth2_sig"], want, 1e-5)
-    assert gt["flow2_sig"].shape == (n, 20, 48, 64)                      # 5 deltas x 2 flow channels x (x, y)
+    # flow (C = 2): the op folds the two channels into the batch -> [2N, 5 deltas x (x, y), H, W], as the reference's tensors
+    assert gt["flow2_sig"].shape == (2 * n, 10, 48, 64)
+    fl2 = ops_ref.depth_to_flow(pyr[2], K_DEMON, rot, tr, True, True)
+    want_f = np.concatenate([ops_ref.scale_invariant_gradient(fl2, [d], [1.0], 0.001) for d in deltas], axis=1)
+    close(gt["flow2_sig"], want_f, 2e-4)
+    # loss_flow2_sig of v2/losses.py:176-177: ONE pointwise l2 over the 10 channels, mean over 2N * H * W
+    pr_f = gt["flow2_sig"] + rng.standard_normal(gt["flow2_sig"].shape).astype(np.float32) * 0.05
+    pr_f[np.isnan(gt["flow2_sig"])] = 0.0
+    got_f = losses.pointwise_l2_loss(pr_f, gt["flow2_sig"], 1e-3)
+    ref_f = ops_ref.pointwise_l2_loss(pr_f, want_f, 1e-3)
+    assert abs(got_f - ref_f) < 1e-4 * ref_f
     pred = gt["depth2_sig"] + rng.standard_normal(gt["depth2_sig"].shape).astype(np.float32) * 0.1
     got = losses.scale_invariant_gradient_loss(pred, gt["depth2_sig"], 1e-3)
     ref = sum(ops_ref.pointwise_l2_loss(pred[:, 2 * i:2 * i + 2], want[:, 2 * i:2 * i + 2], 1e-3) for i in range(5))

@@ -6,8 +6,8 @@
   * photometric known-answer test: warping sculpture image 2 by the reference flow (oracle warp2d) resembles image 1 on
     the reference's visible-pixel mask -- pins sign, channel order and normalisation of warp2d's displacement with
     reference-held images (SURVEY.md section 8c golden use (2));
-  * semantics decided this round: NaN ordering of median3x3_downsample, channel layout of scale_invariant_gradient for
-    C > 1 / several deltas, depth_to_normals.
+  * semantics decided here: NaN ordering of median3x3_downsample, border rule of scale_invariant_gradient (its layout --
+    channels folded into the batch, deltas summed -- follows the lmbspecialops contract), depth_to_normals.
 """
 import os
 
@@ -134,23 +134,44 @@ def test_median_nan_sorts_last():
 
 
 def test_sig_layout_for_channels_and_deltas():
-    """[N,C,H,W] -> [N, C*2*nd, H, W], channel (c*nd + k)*2 + {x,y}; one delta per call + concat (v2/losses.py:76-79) gives the
-    pairs the loss slices (:99-102); C = 2 is the flow case (:343)"""
+    """lmbspecialops contract (SURVEY.md C.6): [N,C,H,W] -> [N*C,2,H,W], the deltas of one call are summed with their weights;
+    one delta per call + concat on axis 1 (v2/losses.py:76-79) gives the (x, y) pairs the loss slices (:99-102); C = 2 is the
+    flow case (:343) and yields a batch of 2N"""
     rng = np.random.default_rng(0)
     u = rng.standard_normal((2, 2, 9, 11)).astype(np.float32)
     deltas, weights = [1, 2, 4], [1.0, 0.5, 2.0]
     full = ops_ref.scale_invariant_gradient(u, deltas, weights, 0.01)
-    assert full.shape == (2, 2 * 2 * 3, 9, 11)
-    for c in range(2):
-        for k, (d, w) in enumerate(zip(deltas, weights)):
-            single = ops_ref.scale_invariant_gradient(u[:, c:c + 1], [d], [w], 0.01)
-            assert single.shape == (2, 2, 9, 11)
-            np.testing.assert_array_equal(full[:, (c * 3 + k) * 2:(c * 3 + k) * 2 + 2], single)
+    assert full.shape == (2 * 2, 2, 9, 11)
+    total = np.zeros_like(full)
+    for d, w in zip(deltas, weights):
+        single = ops_ref.scale_invariant_gradient(u, [d], [w], 0.01)
+        assert single.shape == (4, 2, 9, 11)
+        for b in range(2):
+            for c in range(2):   # row b*C + c of the folded batch is channel c of sample b on its own
+                np.testing.assert_array_equal(single[b * 2 + c], ops_ref.scale_invariant_gradient(u[b:b + 1, c:c + 1], [d], [w], 0.01)[0])
+        total += single
+    np.testing.assert_allclose(full, total, atol=1e-6)
     # direct formula, delta 2, x direction, interior and right border
     s = ops_ref.scale_invariant_gradient(u[:, :1], [2], [0.5], 0.01)
     a, b = u[0, 0, 3, 4], u[0, 0, 3, 6]
     np.testing.assert_allclose(s[0, 0, 3, 4], 0.5 * (b - a) / (abs(a) + abs(b) + 0.01), rtol=1e-6)
     assert s[0, 0, 3, 9] == 0 and s[0, 0, 3, 10] == 0 and s[0, 1, 7, 0] == 0 and s[0, 1, 8, 0] == 0
+
+
+def test_flow_sig_loss_layout_matches_the_reference_call_site():
+    """v2/losses.py:176-177 on a C = 2 tensor: scale_invariant_gradient(flow) is [2N, 10, H, W] and loss_flow2_sig is ONE
+    pointwise_l2_loss over those 10 channels (sqrt of the sum over 10 channels, mean over 2N*H*W) -- not 20 channels over N"""
+    rng = np.random.default_rng(1)
+    n, h, w = 2, 6, 8
+    flow = rng.standard_normal((n, 2, h, w)).astype(np.float32)
+    gt = rng.standard_normal((n, 2, h, w)).astype(np.float32)
+    deltas = [1, 2, 4]
+    sig = lambda t: np.concatenate([ops_ref.scale_invariant_gradient(t, [d], [1.0], 0.001) for d in deltas], axis=1)
+    a, b = sig(flow), sig(gt)
+    assert a.shape == (2 * n, 2 * len(deltas), h, w)
+    want = np.sqrt(((a.astype(np.float64) - b) ** 2).sum(axis=1) + 1e-3).mean()
+    got = ops_ref.pointwise_l2_loss(a, b, 1e-3)
+    assert abs(got - want) < 1e-5 * want
 
 
 def plane_depth(n, d, H, W, K=K_DEMON):
