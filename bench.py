@@ -9,8 +9,10 @@ A "step" is one pass of the hot path over one batch of synthetic pairs already r
 configs[2]: batch 32 per GPU, full pipeline, hipGraph on).  Pairs are independent, so ranks shard the
 batch with no data-path collective (weak scaling: 32 pairs per GPU, configs[3] = 8 x 32); the only
 collective is one RCCL broadcast of the 183 MB weight blob at start-up, outside the timed region.
-Rank 0 prints ONE JSON line.  `roofline` = the single kernel (template instance) with the largest share of the pass and
-`roofline_family` = all conv / deconv / dense launches, both timed per launch with HIP events on the context stream;
+Rank 0 prints ONE JSON line.  `roofline` = the single kernel (template instance) with the largest share of the pass by its own time
+(rocprofv3's convention: split-K reduce launches listed beside it), `roofline_worst` = the kernel with >= 5 % of the pass that is
+furthest below its roofline, `roofline_family` = all conv / deconv / dense launches; all timed per launch with HIP events on the
+context stream, with rocprofv3's average of the same kernel next to it when profiles/ holds one for these kernel sources;
 `cpu_baseline` = the CPU oracle ("TF-CPU-equivalent" PyTorch-CPU restatement) on this box's host cores, rank 0 / N=1 only;
 `extra` = the PCIe-inclusive host-to-host rate.
 """
@@ -93,6 +95,31 @@ def cpu_baseline(weights, budget_s=30.0):
 from demon_amd.kernel_names import rocprof_kernel_name  # noqa: E402
 
 
+def rocprof_stats():
+    """{profile tag: {"avg_ms", "calls", "source"}} from the newest profiles/*_bench_kernel_stats.csv (rocprofv3 --kernel-trace
+    --stats of this command), only when its side file says it was taken on the kernel sources and plans of this tree"""
+    import csv
+    import glob
+    from demon_amd import build as hip_build
+    from demon_amd.kernel_names import kernel_tag
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_kernel_stats.csv")))
+    if not paths:
+        return {}
+    meta_path = paths[-1].replace(".csv", ".meta.json")
+    try:
+        with open(meta_path) as f:
+            if json.load(f).get("csrc_sha") != hip_build.csrc_sha():
+                return {}
+    except (OSError, ValueError):
+        return {}
+    out = {}
+    with open(paths[-1]) as f:
+        for row in csv.DictReader(f):
+            e = out.setdefault(kernel_tag(row["Name"]), {"ns": 0.0, "calls": 0})
+            e["ns"] += float(row["TotalDurationNs"]); e["calls"] += int(row["Calls"])
+    return {t: {"avg_ms": e["ns"] / e["calls"] * 1e-6, "calls": e["calls"], "source": os.path.basename(paths[-1])} for t, e in out.items() if e["calls"]}
+
+
 def flush_c_stdio():
     """fflush(NULL): text that native libraries (RCCL's banner) printed through C stdio must not surface after the JSON line"""
     import ctypes
@@ -157,11 +184,14 @@ def main():
     # product's own C-ABI path (demon_comm_* + demon_broadcast_weights: packed device slab, no host staging on receivers);
     # --weights-bcast torch = torch.distributed.broadcast of the TF-layout blob + demon_set_weights_blob_device
     host_weights = W.synthetic_weights(seed=1, height=height, width=width, version=version) if rank == 0 else None
-    t_bcast, bcast_desc = 0.0, "single process: no broadcast"
+    t_bcast, bcast_desc, bcast_route, rccl_nranks = 0.0, "single process: no broadcast", "none", None
     if distributed:
         from demon_amd import distributed as D
         t_bcast, bcast_desc = D.distribute_weights(ctx, host_weights, rank, world,
                                                    route="rccl" if args.weights_bcast == "rccl" else "torch-gpu")
+        # what RCCL itself says (ncclCommCount through the C ABI): a SCALE record with rccl_nranks == n_gpus proves the slab
+        # really crossed a communicator of that many ranks
+        bcast_route, rccl_nranks = D.LAST_BROADCAST.get("route"), D.LAST_BROADCAST.get("rccl_nranks")
         flush_c_stdio()
     else:
         ctx.set_weights(host_weights)
@@ -225,6 +255,8 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "iterations": args.iterations,
                        "sharding": "independent pairs per rank, no data-path collective",
                        "weights": "synthetic He-normal seed 1; %s, %.1f ms (untimed)" % (bcast_desc, 1e3 * t_bcast),
+                       "weights_broadcast_ms": round(1e3 * t_bcast, 2), "weights_broadcast_route": bcast_route,
+                       "rccl_nranks": rccl_nranks,
                        "launch_plan": plan_src, "plan_setup_s": round(t_tune, 2)},
             "outputs_finite": bool(finite),
         }
@@ -241,27 +273,50 @@ def main():
                 result["gflop_per_pair"] = flops / n / 1e9
                 result["pipeline_mfma_frac"] = value / world * flops / n / (PEAK_FP32_MFMA_TFLOPS * 1e12)
             total_ms = sum(r["ms"] for r in recs)
+            # per template instance, rocprofv3's convention: the kernel's OWN time (ms - reduce_ms); the conv_splitk_reduce
+            # launches that follow some of its launches are listed beside it, not folded in
             by_kernel = {}
             for r in recs:
-                e = by_kernel.setdefault(r["kernel"].split("+")[0], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "splitk_launches": 0})
-                e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["bytes"] += r["bytes"]; e["launches"] += 1
+                e = by_kernel.setdefault(r["kernel"].split("+")[0], {"ms": 0.0, "reduce_ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "splitk_launches": 0})
+                red = r.get("reduce_ms", 0.0) if "+splitk" in r["kernel"] else 0.0
+                e["ms"] += r["ms"] - red; e["reduce_ms"] += red
+                e["flops"] += r["flops"]; e["bytes"] += r["bytes"]; e["launches"] += 1
                 e["splitk_launches"] += 1 if "+splitk" in r["kernel"] else 0
-            dom_tag = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
-            dom = by_kernel[dom_tag]
-            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            # `roofline` = the single kernel with the largest share of the pass (one template instance, as rocprofv3 lists it);
-            # `roofline_family` = all contraction launches together (what round 1 reported as `roofline`)
-            result["roofline"] = {
-                "kernel": rocprof_kernel_name(dom_tag), "tag": dom_tag,
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"], "flops_per_launch": dom["flops"] / dom["launches"],
-                "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
-                "launches_followed_by_splitk_reduce": dom["splitk_launches"],
-                "kernel_time_share": dom["ms"] / total_ms,
-                "timing": "hip events around each launch on the context stream, launches run one after the other (eager), mean of 3 passes; "
-                          "avg_launch_ms includes the split-K reduce launch where one follows",
-            }
+            rocprof = rocprof_stats()
+
+            def roofline_entry(tag):
+                k = by_kernel[tag]
+                achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
+                e = {
+                    "kernel": rocprof_kernel_name(tag), "tag": tag,
+                    "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "algorithmic_bytes_per_launch": k["bytes"] / k["launches"], "flops_per_launch": k["flops"] / k["launches"],
+                    "launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
+                    "kernel_time_share": k["ms"] / total_ms,
+                    "splitk_reduce": {"launches": k["splitk_launches"],
+                                      "avg_ms": k["reduce_ms"] / k["splitk_launches"] if k["splitk_launches"] else 0.0,
+                                      "frac_with_reduce": k["flops"] / ((k["ms"] + k["reduce_ms"]) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                    "timing": "hip events around each launch on the context stream, launches run one after the other (eager), mean of 3 "
+                              "passes; kernel only -- the conv_splitk_reduce launch that follows some launches is timed separately (splitk_reduce)",
+                }
+                rp = rocprof.get(tag)
+                if rp:   # the other clock: rocprofv3 --kernel-trace --stats of this command (graph replay), same kernel sources
+                    e["rocprof_avg_launch_ms"] = rp["avg_ms"]
+                    e["rocprof_calls"] = rp["calls"]
+                    e["rocprof_frac"] = k["flops"] / k["launches"] / (rp["avg_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+                    e["rocprof_source"] = rp["source"]
+                return e
+
+            contraction = {t: k for t, k in by_kernel.items() if k["flops"] > 0}
+            dom_tag = max(contraction, key=lambda t: contraction[t]["ms"])
+            # `roofline` = the single kernel with the largest share of the pass by its own time (one template instance, as rocprofv3
+            # lists it); `roofline_worst` = of the kernels with >= 5 % of the pass, the one furthest below its roofline;
+            # `roofline_family` = all contraction launches together
+            result["roofline"] = roofline_entry(dom_tag)
+            big = [t for t, k in contraction.items() if k["ms"] / total_ms >= 0.05]
+            worst_tag = min(big, key=lambda t: contraction[t]["flops"] / contraction[t]["ms"]) if big else dom_tag
+            result["roofline_worst"] = roofline_entry(worst_tag)
             fam_achieved = flops / (ms * 1e-3) / 1e12
             result["roofline_family"] = {
                 "kernel": "all conv / deconv / dense launches (conv_frag, conv_frag_chain, conv_stream, conv_stream_chain, conv_patch, deconv4, conv_pair, conv_mfma, conv_small kernels)",
@@ -274,6 +329,7 @@ def main():
                 "gflop_per_pair_launched": flops / n / 1e9, "kernel_time_share": ms / total_ms,
             }
             result["kernel_time_shares"] = {k: round(v["ms"] / total_ms, 4) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+            result["kernel_time_shares"]["conv_splitk_reduce (all)"] = round(sum(v["reduce_ms"] for v in by_kernel.values()) / total_ms, 4)
             # HBM bytes per launch cannot be read from inside the process: they come from the rocprofv3 --pmc passes of
             # this same command (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction) summarised by
             # tools/pmc_summary.py into profiles/<round>_pmc_summary.json, which records the hash of the kernel sources it
@@ -292,11 +348,12 @@ def main():
                             result["roofline_family"]["traffic"] = c["hbm_traffic_bytes_per_launch"]
                             result["roofline_family"]["traffic_unit"] = "bytes per launch (%s)" % src
                             result["roofline_family"]["pmc_mfma_busy_frac"] = c.get("mfma_busy_frac")
-                        k = summary.get("kernels", {}).get(dom_tag, {})
-                        if "hbm_traffic_bytes_per_launch" in k:
-                            result["roofline"]["traffic"] = k["hbm_traffic_bytes_per_launch"]
-                            result["roofline"]["traffic_unit"] = "bytes per launch (%s)" % src
-                            result["roofline"]["pmc_mfma_busy_frac"] = k.get("mfma_busy_frac")
+                        for key in ("roofline", "roofline_worst"):
+                            k = summary.get("kernels", {}).get(result[key]["tag"], {})
+                            if "hbm_traffic_bytes_per_launch" in k:
+                                result[key]["traffic"] = k["hbm_traffic_bytes_per_launch"]
+                                result[key]["traffic_unit"] = "bytes per launch (%s)" % src
+                                result[key]["pmc_mfma_busy_frac"] = k.get("mfma_busy_frac")
                     else:
                         result["roofline"]["traffic_note"] = "%s was measured on other kernel sources (%s): not reported" % (
                             os.path.basename(pmc[-1]), summary.get("csrc_sha"))

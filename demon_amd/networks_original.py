@@ -65,7 +65,9 @@ class BootstrapNet(_Net):
         image_pair = self._check(image_pair, self._shape(6, _H, _W), "placeholder_image_pair")
         image2_2 = self._check(image2_2, self._shape(3, _H // 4, _W // 4), "placeholder_image2_2")
         r = self._ctx.bootstrap(_to_nchw(image_pair, self.data_format), _to_nchw(image2_2, self.data_format))
-        return self._outputs(r)
+        out = self._outputs(r)
+        runtime.note_eval(self, {"image_pair": image_pair, "image2_2": image2_2}, out)
+        return out
 
 
 class IterativeNet(_Net):
@@ -85,7 +87,9 @@ class IterativeNet(_Net):
         translation = self._check(translation, (self.batch_size, 3), "placeholder_translation")
         r = self._ctx.iterative(_to_nchw(image_pair, df), _to_nchw(image2_2, df), _to_nchw(depth2, df),
                                 _to_nchw(normal2, df), _to_nchw(rotation, df), _to_nchw(translation, df))
-        return self._outputs(r)
+        out = self._outputs(r)
+        runtime.note_eval(self, {}, out)
+        return out
 
 
 class RefinementNet(_Net):
@@ -95,4 +99,6 @@ class RefinementNet(_Net):
         image1 = self._check(image1, self._shape(3, _H, _W), "placeholder_image1")
         depth2 = self._check(depth2, self._shape(1, _H // 4, _W // 4), "placeholder_depth2")
         r = self._ctx.refine(_to_nchw(image1, self.data_format), _to_nchw(depth2, self.data_format))
-        return {"predict_depth0": _from_nchw(r["predict_depth0"], self.data_format)}
+        out = {"predict_depth0": _from_nchw(r["predict_depth0"], self.data_format)}
+        runtime.note_eval(self, {"image1": image1}, out)
+        return out
