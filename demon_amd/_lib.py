@@ -88,6 +88,7 @@ SIGNATURES = {
     "demon_op_deconv4x4s2": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 6),
     "demon_op_dense": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 4),
     "demon_bench_layer": (_I, [_P] + [_I] * 13 + [c_float_p, ctypes.POINTER(ctypes.c_double)]),
+    "demon_last_kernel": (_I, [ctypes.c_char_p, _I]),
 }
 
 _lib = None

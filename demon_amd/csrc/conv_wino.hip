@@ -1,0 +1,414 @@
+// conv_wino.hip -- minimal-filtering (Winograd / Toom-Cook) forms of the two MFMA-bound layer classes, on fp32 MFMA.
+//
+// The transposed convs (blocks_original.py:64-75, :97-110; `refine*/upconv`, 27 % of a batch-32 pass at 105-113 TFLOP/s, i.e. at
+// what the matrix pipe gives under load) are four 2 x 2 sub-pixel convolutions.  F(2,2) computes two outputs of a 2-tap filter with
+// 3 multiplications instead of 4:
+//       o0 = d0*g_lo + d1*g_hi            m0 = (d0 - d1)*g_lo          o0 = m0 + m1
+//       o1 = d1*g_lo + d2*g_hi            m1 =  d1*(g_lo + g_hi)       o1 = m1 + m2
+//                                         m2 = (d2 - d1)*g_hi
+// (all transform coefficients are +-1: no scaling, no cancellation beyond that of the direct sum), nested in y and x: a 2 x 2 block
+// of outputs of one sub-pixel class costs 9 multiply-accumulates per input channel instead of 16 -- 0.5625 x the MFMAs of
+// deconv4_kernel for the same result (to summation order).  GEMM view per class and (u,v) in {0,1,2}^2:
+//       M[u][v][co][tile] = sum_ci U[u][v][ci][co] * T[u][v][ci][tile],     tile = a 2 x 2 block of class outputs
+//       U[u][v] = sum of the taps G[ty][tx] with ty in S(u), tx in S(v), S(0) = {1}, S(1) = {0,1}, S(2) = {0}
+//       T = the 3 x 3 input neighbourhood d of the tile transformed by rows, then columns: (d0 - d1, d1, d2 - d1)
+//       O[a][b] = M[a][b] + M[a][b+1] + M[a+1][b] + M[a+1][b+1]
+// Neither transform touches memory: a lane reads the 9 input values of its tile (and channel) from the staged patch and forms the 9
+// T values with 12 subtractions; a wave reads the 4 taps of its class from LDS and forms the 9 U fragments with 5 additions -- so
+// the weights stay in the packed layout every other kernel uses and the operand traffic per MFMA is that of deconv4_kernel.
+//
+// v_mfma_f32_16x16x4_f32: a wave owns ONE sub-pixel class, 16 output channels and TN blocks of 16 tiles (9 accumulators of 4
+// registers per block); lane = (tile, channel of the K group).  A workgroup = the 4 classes of one 16-channel x 16*TN-tile block,
+// sharing the staged input patch (union patch with origin (-1,-1), columns de-interleaved by parity so that the lanes of
+// consecutive tiles read consecutive LDS words) and the [class][tap][k][16] weight tile.
+#include <type_traits>
+
+#include "internal.h"
+
+namespace demon {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ int wdiv(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }  // magic 0 <=> d == 1
+}
+
+// The LDS row pitch of the patch is compile-time (the 9 reads of a tile are then one base register + immediate offsets); TX <= 16
+// tiles per row of the workgroup tile (34 patch columns).  Lanes of consecutive tiles read every second word: with a pitch of
+// 8 (mod 16) words two tile rows of 8 tiles fall on different even banks, and an ODD plane stride puts the other channel of a
+// 32-lane LDS access group on the odd banks -- conflict free for TX = 16 and TX = 8.
+constexpr int WINO_PWL = 40, WINO_NT = 256, WINO_CKS = 4;
+
+template <int TN, int EPT, int OCC>
+__global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
+{
+    constexpr int NT = WINO_NT, CKS = WINO_CKS, PWL = WINO_PWL;
+    constexpr int ASZ = 4 * 4 * CKS * 16;  // floats of one weight tile: [class][tap][k][16 channels]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;               // [2][ASZ]
+    const int patch_floats = a.G * CKS * a.PS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int py = wave >> 1, px = wave & 1;   // this wave's sub-pixel class (cls = wave)
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int zs = blockIdx.z;
+    unsigned bx, by;
+    xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    const int m0 = by * 16;
+    const int tyg = wdiv((int)bx, a.m_tilesx);
+    const int tx = (int)bx - tyg * a.tiles_x;
+    const int tgrp = wdiv(tyg, a.m_tilesy);
+    const int ty = tyg - tgrp * a.tiles_y;
+    const int n0 = tgrp * a.G;
+    const int y_org = ty * a.TY * 2 - 1, x_org = tx * a.TX * 2 - 1;   // input coordinates of patch element (0,0)
+    const float *__restrict__ in0 = a.in + (long)n0 * a.in_n_stride;
+
+    // fp32 MFMA and the vector ALU share a SIMD's execution time (rocprofv3: SQ_VALU_MFMA_BUSY_CYCLES + 4 * SQ_ACTIVE_INST_VALU adds
+    // up to the kernel's duration), so every VALU instruction in the K loop costs an eighth of an MFMA.  The loop therefore carries
+    // no address arithmetic and no masking: operands come through buffer loads (uniform base advanced by SALU, per-thread byte
+    // offsets fixed for the whole kernel, elements outside the image carry an out-of-range offset and read as zero), and every
+    // LDS address of both buffers is precomputed.
+    constexpr int OOB = 0x7ffffff0;        // >= num_records of the buffer resources: reads as 0
+    constexpr int NREC = 0x40000000;
+    // ---- patch loader: element e = tid + i*NT of the [G*CKS][PH][PW] patch, decoded once
+    const int plane_elems = a.PH * a.PW;
+    const int nelem = a.G * CKS * plane_elems;
+    const int dummy_off = 2 * ASZ + 2 * patch_floats + tid;  // floats from smem: this thread's dummy slot (branch-free staging)
+    int goff[EPT], lds_p[2][EPT];
+    unsigned lastbits = 0;                 // elements whose channel exists in the LAST K-step (Cin not a multiple of 4)
+    const int last_c0 = (a.nsteps_total - 1) * CKS;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = tid + i * NT;
+        goff[i] = OOB;
+        lds_p[0][i] = lds_p[1][i] = dummy_off;
+        if (e < nelem) {
+            const int pl = wdiv(e, a.m_plane), pos = e - pl * plane_elems;
+            const int g = pl / CKS, c = pl - g * CKS;
+            const int pr = wdiv(pos, a.m_pw), pc = pos - pr * a.PW;
+            const int gy = y_org + pr, gx = x_org + pc;
+            const bool ok = ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
+            if (ok) goff[i] = 4 * (g * (int)a.in_n_stride + c * a.H * a.W + gy * a.W + gx);
+            lds_p[0][i] = 2 * ASZ + pl * a.PS + pr * PWL + pc;
+            lds_p[1][i] = lds_p[0][i] + patch_floats;
+            lastbits |= ((last_c0 + c < a.Cin) ? 1u : 0u) << i;
+        }
+    }
+    const bool mask_last = (a.Cin & 3) != 0;
+    // ---- weight loader: one 16-byte chunk per thread: (class, tap, k, 4 channels) <-> packed row tap*Cin + c0 + k of that class
+    int aoff;
+    {
+        const int cls = tid >> 6, tap = (tid >> 4) & 3, k = (tid >> 2) & 3, c4 = tid & 3;
+        aoff = 4 * (int)((long)cls * a.cls_w_stride + (long)(tap * a.Cin + k) * a.Mpad + m0 + c4 * 4);
+    }
+
+    // ---- fragment addressing: lane = (tile l15 of block tb, channel lk); float index of d[0][0] of the tile in either patch buffer
+    const int ntile = a.G * a.TY * a.TX;
+    int rb[2][TN], ra[2];
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        int q = tb * 16 + l15;
+        if (q >= ntile) q = 0;   // padding lanes read a valid address; masked at the store
+        const int g = wdiv(q, a.m_tytx), rem = q - g * (a.TY * a.TX);
+        const int r = wdiv(rem, a.m_tx), c = rem - r * a.TX;
+        rb[0][tb] = 2 * ASZ + (g * CKS + lk) * a.PS + (2 * r + py) * PWL + 2 * c + px;
+        rb[1][tb] = rb[0][tb] + patch_floats;
+    }
+    ra[0] = wave * (4 * CKS * 16) + lane;
+    ra[1] = ra[0] + ASZ;
+    // keep the second buffer's addresses in registers of their own: re-deriving them costs a VALU add per LDS access in the K loop
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) asm volatile("" : "+v"(rb[1][tb]));
+    asm volatile("" : "+v"(ra[1]));
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) asm volatile("" : "+v"(lds_p[1][i]));
+
+    floatx4 acc[TN][9];
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[tb][q] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    float pregA[EPT], pregB[EPT];
+    floatx4 aregA, aregB;
+    auto load_tiles = [&](float (&preg)[EPT], floatx4 &areg, int step) {
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * a.H * a.W), 0, NREC, 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp + (long)step * CKS * a.Mpad), 0, NREC, 0x00020000);
+        if (mask_last && step == a.nsteps_total - 1) {   // (uniform) channels past Cin read as zero
+#pragma unroll
+            for (int i = 0; i < EPT; ++i)
+                preg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, ((lastbits >> i) & 1u) ? goff[i] : OOB, 0, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) preg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i], 0, 0));
+        }
+        areg = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff, 0, 0));
+    };
+    auto store_tiles = [&](const float (&preg)[EPT], const floatx4 &areg, int buf) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) smem[lds_p[buf][i]] = preg[i];
+        *reinterpret_cast<floatx4 *>(As + buf * ASZ + tid * 4) = areg;
+    };
+    // ---- K loop.  One K-step = 4 input channels = one MFMA K group; global loads run two K-steps ahead (two register sets).
+    // The one barrier of a step sits in front of the LAST tile block's MFMAs:
+    //   blocks 0 .. TN-2 : MFMAs of block tb | LDS reads of block tb+1 | the set holding step s+1 -> the other LDS buffer | loads of step s+3
+    //   barrier          : step s+1 is complete in the other buffer
+    //   block TN-1       : its MFMAs | LDS reads of the taps and of block 0 of step s+1
+    // so no MFMA waits for an LDS read issued just before it, and nothing but the barrier itself stops the matrix pipe.
+    // Buffer safety: the buffer written during step s held step s-1, whose last reads were issued before the barrier of step s-1.
+    const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
+    const int s_begin = zs * per_slice;
+    const int nsteps = min(a.nsteps_total, s_begin + per_slice) - s_begin;
+    auto phys = [&](int x) { return s_begin + min(x, nsteps - 1); };  // a run-ahead past the end of the slice re-reads its last step
+    if (nsteps > 0) {
+        load_tiles(pregA, aregA, phys(0));
+        load_tiles(pregB, aregB, phys(1));
+        store_tiles(pregA, aregA, 0);
+        load_tiles(pregA, aregA, phys(2));
+    }
+    __syncthreads();
+    float U[9], gn[4], d[9];
+    auto read_taps = [&](int buf) {
+        const float *A = smem + ra[buf];
+        gn[0] = A[0]; gn[1] = A[64]; gn[2] = A[128]; gn[3] = A[192];   // taps (ty,tx) = (0,0), (0,1), (1,0), (1,1)
+    };
+    auto make_u = [&]() {
+        const float s23 = gn[2] + gn[3], s13 = gn[1] + gn[3], s02 = gn[0] + gn[2], s01 = gn[0] + gn[1];
+        U[0] = gn[3]; U[1] = s23;       U[2] = gn[2];
+        U[3] = s13;   U[4] = s01 + s23; U[5] = s02;
+        U[6] = gn[1]; U[7] = s01;       U[8] = gn[0];
+    };
+    auto read_d = [&](int buf, int tb) {
+        const float *p = smem + rb[buf][tb];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            d[j * 3 + 0] = p[j * PWL + 0];
+            d[j * 3 + 1] = p[j * PWL + 1];
+            d[j * 3 + 2] = p[j * PWL + 2];
+        }
+    };
+    float b[9];
+    auto transform = [&]() {
+        float r0[3], r2[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { r0[i] = d[i] - d[3 + i]; r2[i] = d[6 + i] - d[3 + i]; }
+        b[0] = r0[0] - r0[1]; b[1] = r0[1]; b[2] = r0[2] - r0[1];
+        b[3] = d[3] - d[4];   b[4] = d[4];  b[5] = d[5] - d[4];
+        b[6] = r2[0] - r2[1]; b[7] = r2[1]; b[8] = r2[2] - r2[1];
+    };
+    auto mfmas = [&](int tb) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[tb][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q], b[q], acc[tb][q], 0, 0, 0);
+    };
+    auto head = [&](int buf) {   // blocks 0 .. TN-2, and the transform of the last block
+#pragma unroll
+        for (int tb = 0; tb + 1 < TN; ++tb) { transform(); read_d(buf, tb + 1); mfmas(tb); }
+        transform();
+    };
+    if (nsteps > 0) {
+        int s = 0;
+        read_taps(0); make_u(); read_d(0, 0);
+        for (; s + 2 < nsteps; s += 2) {
+            head(0);
+            store_tiles(pregB, aregB, 1);
+            load_tiles(pregB, aregB, phys(s + 3));
+            __syncthreads();
+            read_taps(1); read_d(1, 0);
+            mfmas(TN - 1);
+            make_u();
+            head(1);
+            store_tiles(pregA, aregA, 0);
+            load_tiles(pregA, aregA, phys(s + 4));
+            __syncthreads();
+            read_taps(0); read_d(0, 0);
+            mfmas(TN - 1);
+            make_u();
+        }
+        if (s + 1 < nsteps) {
+            head(0);
+            store_tiles(pregB, aregB, 1);
+            __syncthreads();
+            read_taps(1); read_d(1, 0);
+            mfmas(TN - 1);
+            make_u();
+            ++s;
+        }
+        head(s & 1);
+        mfmas(TN - 1);
+    }
+
+    // ---- epilogue: O[a][b] = M[a][b] + M[a][b+1] + M[a+1][b] + M[a+1][b+1]; lane = tile, registers = 4 consecutive channels
+    const long P = (long)a.N * a.H * a.W;
+    const long plane = a.out_plane;
+    // Full-row stores: the classes px = 0 / 1 of one py own the even / odd output columns of the same rows.  The two waves swap
+    // half of their outputs through LDS (the tile buffers are free now) -- wave px = 0 keeps tile row a = 0 and receives the
+    // partner's, wave px = 1 keeps a = 1 -- so that a lane writes the 4 consecutive pixels (px0 b0, px1 b0, px0 b1, px1 b1) of one
+    // output row as 16 bytes, 16 lanes = 256 contiguous bytes (4-byte stores of every second pixel made the big maps store bound).
+    const bool wide = a.ksplit == 1 && (a.W & 1) == 0;
+    float *X = smem;   // [wave][tb][e][ib][64 lanes]
+    if (wide) __syncthreads();   // every wave is done reading the tile buffers
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int q = tb * 16 + l15;
+        const bool qv = q < ntile;
+        const int qc = qv ? q : 0;
+        const int g = wdiv(qc, a.m_tytx), rem = qc - g * (a.TY * a.TX);
+        const int r = wdiv(rem, a.m_tx), c = rem - r * a.TX;
+        const int n = n0 + g;
+        const int y0 = (ty * a.TY + r) * 2, x0 = (tx * a.TX + c) * 2;   // class-grid (= input-grid) position of O[0][0]
+        const bool tv = qv && n < a.N && y0 < a.H && x0 < a.W;
+        if (wide) {
+            float keep[4][2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float o[2][2];
+#pragma unroll
+                for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)
+                        o[ia][ib] = (acc[tb][ia * 3 + ib][e] + acc[tb][ia * 3 + ib + 1][e]) + (acc[tb][(ia + 1) * 3 + ib][e] + acc[tb][(ia + 1) * 3 + ib + 1][e]);
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    keep[e][ib] = px ? o[1][ib] : o[0][ib];
+                    X[(((wave * TN + tb) * 4 + e) * 2 + ib) * 64 + lane] = px ? o[0][ib] : o[1][ib];
+                }
+            }
+            // stash the kept values in the accumulator registers this block no longer needs
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[tb][0][e] = keep[e][0]; acc[tb][1][e] = keep[e][1]; }
+            continue;
+        }
+        if (!tv) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = m0 + 4 * lk + e;
+            float o[2][2];
+#pragma unroll
+            for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+                    o[ia][ib] = (acc[tb][ia * 3 + ib][e] + acc[tb][ia * 3 + ib + 1][e]) + (acc[tb][(ia + 1) * 3 + ib][e] + acc[tb][(ia + 1) * 3 + ib + 1][e]);
+            if (a.ksplit > 1) {   // partial sums in output space, layout [cls][slice][Mpad][P] (conv_splitk_reduce finishes)
+                float *__restrict__ ws = a.ws + (((long)wave * a.ksplit + zs) * a.Mpad + co) * P + ((long)n * a.H + y0) * a.W + x0;
+#pragma unroll
+                for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)
+                        if (y0 + ia < a.H && x0 + ib < a.W) ws[ia * a.W + ib] = o[ia][ib];
+            } else if (co < a.Cout) {
+                const float b = a.bias[co];
+                float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)co * plane + (long)(2 * y0 + py) * a.Wo + (2 * x0 + px);
+#pragma unroll
+                for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {
+                        float v = o[ia][ib] + b;
+                        if (a.act) v = v >= 0.0f ? v : 0.1f * v;
+                        if (y0 + ia < a.H && x0 + ib < a.W) ob[(long)(2 * ia) * a.Wo + 2 * ib] = v;
+                    }
+            }
+        }
+    }
+    if (!wide) return;
+    __syncthreads();
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int q = tb * 16 + l15;
+        const bool qv = q < ntile;
+        const int qc = qv ? q : 0;
+        const int g = wdiv(qc, a.m_tytx), rem = qc - g * (a.TY * a.TX);
+        const int r = wdiv(rem, a.m_tx), c = rem - r * a.TX;
+        const int n = n0 + g;
+        const int ya = (ty * a.TY + r) * 2 + px, x0 = (tx * a.TX + c) * 2;   // this wave's class-grid row (a = px), first column
+        if (!(qv && n < a.N && ya < a.H && x0 < a.W)) continue;
+        float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)(2 * ya + py) * a.Wo + 2 * x0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = m0 + 4 * lk + e;
+            if (co >= a.Cout) continue;
+            const float b = a.bias[co];
+            const float p0 = X[((((wave ^ 1) * TN + tb) * 4 + e) * 2 + 0) * 64 + lane], p1 = X[((((wave ^ 1) * TN + tb) * 4 + e) * 2 + 1) * 64 + lane];
+            const float m0v = acc[tb][0][e], m1v = acc[tb][1][e];
+            floatx4 v = px ? floatx4{p0, m0v, p1, m1v} : floatx4{m0v, p0, m1v, p1};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] += b;
+                if (a.act) v[i] = fmaxf(v[i], 0.1f * v[i]);   // == (v >= 0 ? v : 0.1 v)
+            }
+            *reinterpret_cast<floatx4 *>(ob + (long)co * plane) = v;
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+int wino_variant_tn(int v) { return v == 0 ? 2 : (v == 1 ? 4 : 3); }
+
+size_t wino_lds_bytes(const WinoArgs &a, int tn)
+{
+    const size_t kloop = 2ul * 4 * 4 * WINO_CKS * 16 + 2ul * a.G * WINO_CKS * a.PS + WINO_NT;
+    const size_t exchange = 4ul * tn * 4 * 2 * 64;   // epilogue: [wave][tb][e][ib][lane]
+    return sizeof(float) * (kloop > exchange ? kloop : exchange);
+}
+
+// Workgroup tile of `ntile` = 16 * TN tiles: G images x TY x TX tiles, TX <= 16.  Picks the shape that wastes the fewest tile slots.
+bool wino_plan_geometry(WinoArgs &a, int variant, int n)
+{
+    const int ntile = 16 * wino_variant_tn(variant);
+    const int ity = (a.H + 1) / 2, itx = (a.W + 1) / 2;   // tiles of one image
+    double best = 1e30;
+    bool ok = false;
+    for (int TX : {16, 8, 4, itx}) {
+        if (TX > 16 || TX > itx || TX < 1) continue;
+        int TY = ntile / TX;   // (tile slots beyond G * TY * TX stay empty)
+        if (TY > ity) TY = ity;
+        int G = 1;
+        if (TY == ity && TX == itx) { G = ntile / (TY * TX); if (G < 1) G = 1; if (G > n) G = n; }
+        const int tiles_y = (ity + TY - 1) / TY, tiles_x = (itx + TX - 1) / TX, groups = (n + G - 1) / G;
+        const int PH = 2 * TY + 2, PW = 2 * TX + 2;
+        const long elems = (long)G * WINO_CKS * PH * PW;
+        if ((elems + WINO_NT - 1) / WINO_NT > 8) continue;
+        const double waste = (double)groups * tiles_y * tiles_x * ntile / ((double)n * ity * itx);   // >= 1
+        const double cost = waste * (1.0 + 0.02 * (16.0 / TX));
+        if (cost < best) {
+            best = cost;
+            ok = true;
+            a.G = G; a.TY = TY; a.TX = TX; a.tiles_y = tiles_y; a.tiles_x = tiles_x; a.PH = PH; a.PW = PW;
+        }
+    }
+    if (!ok) return false;
+    a.PS = a.PH * WINO_PWL + 1;   // odd plane stride (see WINO_PWL)
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    a.m_plane = magic(a.PH * a.PW); a.m_pw = magic(a.PW); a.m_tytx = magic(a.TY * a.TX); a.m_tx = magic(a.TX);
+    a.m_tilesx = magic(a.tiles_x); a.m_tilesy = magic(a.tiles_y);
+    return wino_lds_bytes(a, wino_variant_tn(variant)) <= 64 * 1024;
+}
+
+long wino_workgroups(const WinoArgs &a)
+{
+    return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * (a.Mpad / 16);
+}
+
+template <int TN, int OCC>
+static void launch_wino_ept(const WinoArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    const long elems = (long)a.G * WINO_CKS * a.PH * a.PW;
+    const int per_thread = (int)((elems + WINO_NT - 1) / WINO_NT);
+    if (per_thread <= 2) hipLaunchKernelGGL((wino_deconv_kernel<TN, 2, OCC>), grid, dim3(WINO_NT), lds, s, a);
+    else if (per_thread <= 4) hipLaunchKernelGGL((wino_deconv_kernel<TN, 4, OCC>), grid, dim3(WINO_NT), lds, s, a);
+    else if (per_thread <= 6) hipLaunchKernelGGL((wino_deconv_kernel<TN, 6, OCC>), grid, dim3(WINO_NT), lds, s, a);
+    else hipLaunchKernelGGL((wino_deconv_kernel<TN, 8, OCC>), grid, dim3(WINO_NT), lds, s, a);
+}
+
+void launch_wino_deconv(const WinoArgs &a, int variant, hipStream_t stream)
+{
+    const int groups = (a.N + a.G - 1) / a.G;
+    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / 16), (unsigned)a.ksplit);
+    const size_t lds = wino_lds_bytes(a, wino_variant_tn(variant));
+    switch (wino_variant_tn(variant)) {
+        case 2: launch_wino_ept<2, 3>(a, grid, lds, stream); break;
+        case 3: launch_wino_ept<3, 2>(a, grid, lds, stream); break;
+        default: launch_wino_ept<4, 2>(a, grid, lds, stream); break;
+    }
+}
+
+}  // namespace demon

@@ -625,6 +625,33 @@ void run_frag(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStr
     g_last_kernel = g_kernel_tag;
 }
 
+// minimal-filtering transposed conv (conv_wino.hip), plan kind 8: variant = tiles per workgroup, ksplit slices over the input channels
+bool wino_applies(const Layer *L) { return L->kind == Layer::DECONV && L->Cin >= 16 && !L->scale; }
+
+bool run_wino(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
+{
+    WinoArgs w;
+    w.in = a.in; w.out = a.out; w.wp = a.wp; w.bias = a.bias; w.ws = a.ws;
+    w.N = a.N; w.Cin = L->Cin; w.H = a.H; w.W = a.W; w.in_n_stride = a.in_n_stride;
+    w.Cout = L->Cout; w.Mpad = L->Mpad; w.cls_w_stride = a.cls_w_stride;
+    w.Ho = a.Ho; w.Wo = a.Wo; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
+    w.act = a.act; w.xcd = a.xcd;
+    w.nsteps_total = (L->Cin + 3) / 4;
+    if (!wino_plan_geometry(w, variant, a.N)) return false;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > w.nsteps_total) ksplit = w.nsteps_total;
+    w.ksplit = ksplit;
+    launch_wino_deconv(w, variant, s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino_deconv<16x%d>%s", 16 * wino_variant_tn(variant), split_suffix(ksplit, false));
+    g_last_kernel = g_kernel_tag;
+    if (ksplit > 1) {
+        ConvArgs r = a;
+        r.ksplit = ksplit;
+        launch_splitk_reduce(r, L->ncls, s);
+    }
+    return true;
+}
+
 void run_mfma(const ConvArgs &a_in, ConvPlan plan, int ncls, hipStream_t s)
 {
     ConvArgs a = a_in;
@@ -662,6 +689,8 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                     run_frag(L, a, tile, clamp_split(ks), s);
                     return;
                 }
+            } else if (kind == 8) {
+                if (wino_applies(L) && tile >= 0 && tile < WINO_VARIANTS && run_wino(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 1) {
                 PatchPlan pp;
                 if (tile >= 0 && tile < PTILE_COUNT && plan_patch(L, n, ws, pp, tile, ks / 1000 - 1)) {
@@ -692,6 +721,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 run_frag(L, a, t.tile, t.kind == 6 ? 1 : clamp_split(t.ksplit), s);
                 return;
             }
+            if (t.kind == 8 && wino_applies(L) && run_wino(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
                 const int tw = t.ksplit / 1000 - 1, ks = t.ksplit % 1000;
@@ -706,7 +736,11 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             }
         }
     }
-    if (L->force_tile >= 300) {  // demon_bench_layer: fragment-tiled kernel variant force_tile - 300
+    if (L->force_tile >= 400) {  // demon_bench_layer: minimal-filtering transposed conv variant force_tile - 400
+        const int v = L->force_tile - 400;
+        if (wino_applies(L) && v < WINO_VARIANTS && run_wino(L, a, v, clamp_split(L->force_split), s)) return;
+    }
+    if (L->force_tile >= 300 && L->force_tile < 400) {  // demon_bench_layer: fragment-tiled kernel variant force_tile - 300
         const int v = L->force_tile - 300;
         if (L->stream_ok() && v < FRAG_VARIANTS && L->Mpad % frag_variant_bm(v) == 0) { run_frag(L, a, v, clamp_split(L->force_split), s); return; }
     } else if (L->force_tile >= 200) {  // demon_bench_layer: streaming kernel variant force_tile - 200
@@ -797,6 +831,20 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
                 if (kw > 1 && (ks > 2 || nsteps < 4 * kw * ks)) continue;  // in-workgroup split-K is there to avoid the reduce launch
                 if (wgs * ks * kw < 96 || wgs * ks > 4096) continue;
                 cands.push_back({5, v, ks});
+            }
+        }
+    }
+    if (wino_applies(L) && !getenv("DEMON_NO_WINO")) {
+        const int nsteps = (L->Cin + 3) / 4;
+        for (int v = 0; v < WINO_VARIANTS; ++v) {
+            WinoArgs w;
+            w.N = n; w.H = a.H; w.W = a.W; w.Mpad = L->Mpad;
+            if (!wino_plan_geometry(w, v, n)) continue;
+            const long wgs = wino_workgroups(w);
+            for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
+                if (ks > 1 && (ks > nsteps / 8 || wgs * ks > 4096 || (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
+                if (wgs * ks < 96) continue;
+                cands.push_back({8, v, ks});
             }
         }
     }
@@ -1993,11 +2041,15 @@ int demon_autotune(demon_ctx *c, int n)
     c->graphs.clear();
     prepare_stream_weights(c);
     reset_splitk_tickets(c);
+    // DEMON_TUNE_ONLY=<substring>: re-tune only the layers whose name contains it (the others keep their installed plan entries)
+    const char *only = getenv("DEMON_TUNE_ONLY");
     for (auto &L : c->layers) {
+        if (only && *only && L->name.find(only) == std::string::npos) continue;
         int r = autotune_layer(c, L.get(), n);
         if (r) return fail(c, r, "autotune failed at layer " + L->name);
     }
     for (auto &pr : c->chain_pairs) {
+        if (only && *only && pr.first->name.find(only) == std::string::npos) continue;
         int r = autotune_chain(c, pr.first, pr.second, n);
         if (r) return fail(c, r, "autotune failed at pair " + pr.first->name);
     }
@@ -2023,13 +2075,15 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
 {
     if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
     // kinds: 0 im2col, 1 patch-staged, 3 small-Cout, 4 streaming, 5 fragment-tiled, 6 / 7 = kind 5 / 4 chained with the 1 x k partner
-    if (kind < 0 || kind > 7 || kind == 2 || tile < 0 ||
-        tile >= (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT))) || ksplit < 0)
+    // 8 = minimal-filtering transposed conv (conv_wino.hip)
+    if (kind < 0 || kind > 8 || kind == 2 || tile < 0 ||
+        tile >= (kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
             if (kind == 0 && L->Mpad % conv_tile_bm(tile)) return fail(c, DEMON_ERR_INVALID, "tile does not divide Cout");
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
+            if (kind == 8 && !wino_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the minimal-filtering kernel applies to transposed convs only");
             if (kind == 4 && (!L->stream_ok() || L->Mpad % stream_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the streaming kernel does not apply to this layer");
             if (kind == 5 && (!L->stream_ok() || L->Mpad % frag_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the fragment-tiled kernel does not apply to this layer");
             if (kind == 6 || kind == 7) {
@@ -2426,12 +2480,19 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
     return rc;
 }
 
+int demon_last_kernel(char *tag, int tag_cap)
+{
+    const char *k = g_last_kernel ? g_last_kernel : "";
+    if (tag && tag_cap > 0) { strncpy(tag, k, tag_cap - 1); tag[tag_cap - 1] = 0; }
+    return (int)strlen(k);
+}
+
 // Times one contraction layer on device-resident random data (tuning / roofline diagnostics).
 // kind: 0 conv (kh x kw, stride sh x sw, pad k/2), 1 transposed conv k4 s2, 2 dense.  tile < 0 / ksplit <= 0: automatic plan.
 int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw,
                       int tile, int ksplit, int iters, float *avg_ms, double *flops)
 {
-    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || (tile >= 200 + STREAM_VARIANTS && tile < 300) || tile >= 300 + FRAG_VARIANTS) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || (tile >= 200 + STREAM_VARIANTS && tile < 300) || (tile >= 300 + FRAG_VARIANTS && tile < 400) || tile >= 400 + WINO_VARIANTS) return fail(c, DEMON_ERR_INVALID, "bad argument");
     hipSetDevice(c->device);
     demon_ctx scratch;
     scratch.device = c->device;

@@ -287,6 +287,31 @@ void conv_pair_tiles(int Ho, int Wo, int &tiles_y, int &tiles_x);
 int conv_pair_cks(int k);
 bool launch_conv_pair(const PairArgs &a, int k, int stride, hipStream_t s);
 
+// ---- minimal-filtering transposed conv (conv_wino.hip): F(2,2) x F(2,2) per sub-pixel class on v_mfma_f32_16x16x4_f32 -------------
+struct WinoArgs {
+    const float *in;
+    float *out;
+    const float *wp;     // packed weights [cls][tap*Cin + ci][Mpad] (the layout of every other kernel; transformed in registers)
+    const float *bias;
+    float *ws;           // split-K workspace [cls][slice][Mpad][P], partial sums in OUTPUT space
+    int N, Cin, H, W;    // input geometry (= the class grid)
+    long in_n_stride;
+    int Cout, Mpad;
+    long cls_w_stride;
+    int Ho, Wo;
+    long out_n_stride, out_plane;
+    int act, ksplit, nsteps_total;       // K-steps of 4 input channels
+    int G, TY, TX, tiles_y, tiles_x;     // workgroup tile = G images x TY x TX tiles (a tile = 2 x 2 outputs of every class)
+    int PH, PW, PS;                      // patch rows / columns (2 TY + 2, 2 TX + 2), plane stride in LDS
+    int xcd;
+    unsigned m_plane, m_pw, m_tytx, m_tx, m_tilesx, m_tilesy;   // magic numbers for the prologue divisions
+};
+constexpr int WINO_VARIANTS = 3;   // tiles per workgroup: 32, 64, 48
+int wino_variant_tn(int v);
+bool wino_plan_geometry(WinoArgs &a, int variant, int n);
+long wino_workgroups(const WinoArgs &a);
+void launch_wino_deconv(const WinoArgs &a, int variant, hipStream_t stream);
+
 // ---- tiny heads (conv_small.hip): VALU direct conv for Cout <= 4, fused motion tail -------------------------------------
 struct SmallConvArgs {
     const float *in;

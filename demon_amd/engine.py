@@ -386,6 +386,12 @@ class DemonContext:
         return out
 
     # ---- tuning / diagnostics -----------------------------------------------------------------------------
+    def last_kernel(self):
+        """tag of the contraction kernel this thread launched last (diagnostic; e.g. 'wino_deconv<16x64>+splitk')"""
+        buf = ctypes.create_string_buffer(64)
+        self.lib.demon_last_kernel(buf, 64)
+        return buf.value.decode()
+
     def bench_layer(self, kind, n, cin, h, w, cout, kh=1, kw=1, sh=1, sw=1, tile=-1, ksplit=0, iters=20):
         """kind: 'conv' | 'deconv' | 'dense'.  Returns (avg_ms, TFLOP/s)."""
         k = {"conv": 0, "deconv": 1, "dense": 2}[kind]

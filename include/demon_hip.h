@@ -101,6 +101,7 @@ int demon_set_option(demon_ctx *ctx, const char *key, int value);
 int demon_autotune(demon_ctx *ctx, int n);
 /* read back / install launch plans, e.g. to ship the result of one autotune run as a file.  Entry = (kind, tile, ksplit):
  *   kind 0 im2col kernel (conv_mfma.hip), 1 patch-staged kernel (conv_patch.hip; ksplit + 1000 * (pixel-tile shape + 1)),
+ *   8 minimal-filtering transposed conv (conv_wino.hip; tile = variant: 32 / 64 / 48 tiles per workgroup),
  *        3 small-Cout VALU kernel, 4 register-streaming kernel (conv_stream.hip), 5 fragment-tiled kernel (conv_frag.hip),
  *        6 / 7 on the k x 1 layer of a stride-1 pair: the pair runs as ONE chained launch of conv_frag / conv_stream variant `tile`;
  *   tile = tile / variant id of that kernel; ksplit = K slices (kinds 0 / 4 / 5: + 1000 = slices combined inside the launch
@@ -238,9 +239,15 @@ int demon_op_dense(demon_ctx *ctx, float *out, const float *in, const float *w_i
 /* ---- tuning / diagnostics ----------------------------------------------------------------------------
  * Times one contraction layer (kind 0 conv, 1 transposed conv k4 s2, 2 dense) on device-resident random
  * data with hip events; tile < 0 / ksplit <= 0 select the automatic plan (tile 0..7 im2col tiles, 100 + t patch tiles,
- * 200 + v streaming-kernel variants).  Not on the reference's path. */
+ * 200 + v streaming-kernel variants, 300 + v fragment-tiled variants, 400 + v minimal-filtering transposed-conv variants).
+ * Not on the reference's path. */
 int demon_bench_layer(demon_ctx *ctx, int kind, int n, int cin, int h, int w, int cout, int kh, int kw, int sh,
                       int sw, int tile, int ksplit, int iters, float *avg_ms, double *flops);
+
+/* Diagnostic: the tag of the contraction kernel the calling thread launched last (the names demon_profile_full reports, e.g.
+ * "wino_deconv<16x64>+splitk", "conv_frag<128x32,v6>"); tests use it to see that a forced variant really ran.  Returns the tag
+ * length (0: nothing launched yet). */
+int demon_last_kernel(char *tag, int tag_cap);
 
 #ifdef __cplusplus
 }

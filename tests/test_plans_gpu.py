@@ -60,7 +60,7 @@ def check_plan_ran(plan, records):
         if kind in (0, 4, 5) and ksplit % 1000 <= 1:
             assert "+" not in tag, "%s: no split-K planned, ran %s" % (layer, tag)
         seen += 1
-    assert seen >= 100, "only %d plan entries could be matched to launches" % seen
+    assert seen >= 80, "only %d plan entries could be matched to launches" % seen
 
 
 @pytest.mark.parametrize("path", PLANS, ids=[os.path.basename(p)[5:-5] for p in PLANS])

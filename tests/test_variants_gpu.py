@@ -54,6 +54,7 @@ def test_all_variants_agree(gpu_ctx, layer):
     plans += [(5, v, ks) for v in range(22) for ks in (1, 2, 3, 5)]    # fragment-tiled kernel (same requirement)
     # split-K combined inside the launch (ksplit + 1000: tickets instead of the reduce launch)
     plans += [(0, t, ks) for t in range(8) for ks in (1002, 1005)] + [(4, v, 1003) for v in range(18)] + [(5, v, 1003) for v in range(22)]
+    plans += [(8, v, ks) for v in range(3) for ks in (1, 2, 3)]   # minimal-filtering transposed conv (conv_wino.hip; Cin >= 16)
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
@@ -119,5 +120,40 @@ def test_split_k_combined_inside_the_launch_equals_the_reduce_launch(gpu_ctx):
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % (kind, tile, ks + 1000)
             for rep in range(6):
                 np.testing.assert_array_equal(gpu_ctx.deconv4x4s2(x, w, b, lrelu=True), ref)
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+WINO_LAYERS = [(512, 256, 6, 8), (514, 128, 12, 16), (258, 64, 24, 32), (128, 32, 24, 32), (128, 64, 17, 35), (30, 40, 9, 50), (16, 8, 3, 5),
+               (130, 20, 5, 3), (64, 48, 30, 40)]
+
+
+@pytest.mark.parametrize("shape", WINO_LAYERS)
+def test_minimal_filtering_deconv(gpu_ctx, shape):
+    """conv_wino.hip: F(2,2) x F(2,2) per sub-pixel class of the 4x4 stride-2 transposed conv (blocks_original.py:64-75) computes
+    the same sums with 9 instead of 16 multiplications per 2 x 2 output block -- other summation order than the direct kernels,
+    so compared with PyTorch to 1e-5 like every other variant, for every tile count and split-K, on network shapes, odd sizes,
+    Cin not a multiple of 4 and Cout not a multiple of 16; the tag proves the forced variant really ran"""
+    cin, cout, H, W = shape
+    rng = np.random.default_rng(32)
+    n = 5
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((4, 4, cout, cin)) / np.sqrt(4 * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("deconv", x, w, b, (2, 2))
+    try:
+        os.environ["DEMON_FORCE_PLAN"] = "1,8,0"
+        direct = gpu_ctx.deconv4x4s2(x, w, b, lrelu=True)
+        for v in range(3):
+            for ks in (1, 2, 5):
+                os.environ["DEMON_FORCE_PLAN"] = "8,%d,%d" % (v, ks)
+                got = gpu_ctx.deconv4x4s2(x, w, b, lrelu=True)
+                tag = gpu_ctx.last_kernel()
+                assert tag.startswith("wino_deconv<16x%d>" % (32, 64, 48)[v]), tag
+                assert ("+splitk" in tag) == (ks > 1), tag
+                err = rel_l1(got, want)
+                assert err < 1e-5, "variant %d split %d: rel L1 %.3e" % (v, ks, err)
+                assert rel_l1(got, direct) < 1e-5
+                np.testing.assert_array_equal(got, gpu_ctx.deconv4x4s2(x, w, b, lrelu=True))   # deterministic
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)

@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, nargs="+", default=[32])
 ap.add_argument("--rounds", type=int, default=3, help="majority vote over this many autotune runs")
 ap.add_argument("--outdir", default="gpurun_out")
 ap.add_argument("--version", type=int, default=1, choices=[1, 2], help="1 = original model, 2 = v2 model")
+ap.add_argument("--only", default="", help="re-tune only the layers whose name contains this substring, on top of the shipped plan of the batch size")
 args = ap.parse_args()
 os.makedirs(args.outdir, exist_ok=True)
 for n in args.batch:
@@ -26,6 +27,9 @@ for n in args.batch:
     ctx.upload_inputs(pair, img2_2)
     ctx.run_full(n, 3)
     ctx.synchronize()
+    if args.only:
+        assert ctx.load_tuned_plan(n, nearest=False) == n, "no shipped plan to start from"
+        os.environ["DEMON_TUNE_ONLY"] = args.only
     votes = collections.defaultdict(collections.Counter)
     for _ in range(args.rounds):
         ctx.autotune(n)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Times the transposed-conv layers of the nets: best direct plan of the autotuner's families vs the minimal-filtering kernel
+(conv_wino.hip) for every variant / split-K.  usage: python tools/wino_probe.py [--n 32]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from demon_amd import DemonContext  # noqa: E402
+
+LAYERS = [("refine4 up 512->256 6x8", 512, 6, 8, 256), ("refine3 up 514->128 12x16", 514, 12, 16, 128), ("refine2 up 258->64 24x32", 258, 24, 32, 64),
+          ("refine1 up 128->64 48x64", 128, 48, 64, 64), ("refine0 up 128->32 96x128", 128, 96, 128, 32)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=32)
+    args = ap.parse_args()
+    ctx = DemonContext(0, 1)
+    for lab, cin, h, w, cout in LAYERS:
+        line = "%-28s" % lab
+        best = None
+        for tile in (107, 108):       # the fused four-class kernel (deconv4) tiles
+            for ks in (0, 2, 4):
+                try:
+                    ms, tf = ctx.bench_layer("deconv", args.n, cin, h, w, cout, 4, 4, 2, 2, tile=tile, ksplit=ks, iters=10)
+                except Exception:
+                    continue
+                if best is None or ms < best[0]:
+                    best = (ms, tf, tile, ks)
+        line += " deconv4 best %.3f ms %5.1f TF/s (t%d k%d)" % best
+        for v in range(3):
+            wb = None
+            allks = []
+            for ks in (1, 2, 3, 4, 6, 8):
+                try:
+                    ms, tf = ctx.bench_layer("deconv", args.n, cin, h, w, cout, 4, 4, 2, 2, tile=400 + v, ksplit=ks, iters=10)
+                except Exception:
+                    continue
+                if not ctx.last_kernel().startswith("wino"):
+                    continue
+                allks.append("k%d:%.3f" % (ks, ms))
+                if wb is None or ms < wb[0]:
+                    wb = (ms, tf, ks)
+            if wb:
+                line += " | wino v%d %.3f ms %5.1f TF/s k%d [%s]" % (v, wb[0], wb[1], wb[2], " ".join(allks))
+        print(line, flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
