@@ -18,7 +18,7 @@ def csrc_sha():
     import glob
     import hashlib
     h = hashlib.sha1()
-    files = [os.path.join(CSRC, n) for n in sorted(SOURCES) if n != "demon_api.hip"] + [os.path.join(CSRC, "internal.h")]
+    files = [os.path.join(CSRC, n) for n in sorted(SOURCES) if n != "demon_api.hip"] + [os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "wino1d_tables.h")]
     files += sorted(glob.glob(os.path.join(HERE, "tuned", "*.json")))
     for path in files:
         with open(path, "rb") as f:
@@ -45,7 +45,7 @@ def build(force=False, verbose=False, extra_flags=(), tag=""):
     object files); the product library is the untagged build"""
     hipcc = _hipcc()
     out = OUT if not tag else OUT.replace(".so", "_%s.so" % tag)
-    headers = [os.path.join(CSRC, "internal.h"), os.path.join(HERE, "..", "include", "demon_hip.h")]
+    headers = [os.path.join(CSRC, "internal.h"), os.path.join(CSRC, "wino1d_tables.h"), os.path.join(HERE, "..", "include", "demon_hip.h")]
     objs = []
     jobs = []
     for src in SOURCES:

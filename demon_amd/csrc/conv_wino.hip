@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "internal.h"
+#include "wino1d_tables.h"
 
 namespace demon {
 
@@ -593,6 +594,225 @@ __global__ __launch_bounds__(256) void wino3_repack_kernel(float *__restrict__ w
     }
 }
 
+// =====================================================================================================================================
+// k x 1 / 1 x k convolutions (the separable pairs of helpers.py:105-153): two consecutive outputs along the filter axis from one
+// window of inputs with fewer multiplications -- F(2,3) for the 3-tap stride-1 layers (4 instead of 6), and for the stride-2 layers
+// the polyphase split (even / odd input samples see the even / odd taps as stride-1 filters) with F(2,re) + F(2,ro): 7 instead of 10
+// (5 taps), 9 instead of 14 (7 taps), 11 instead of 18 (9 taps).  Transforms: wino1d_tables.h (generated, checked in exact
+// rationals).  Structure as wino_conv3_kernel: the threads of a workgroup transform every (tile, channel) window ONCE at staging time
+// and write the NUV values to LDS ([e][k][tile]); WM waves owning different 16-channel blocks read them as the MFMA B operand.
+//   AXIS 0: k x 1 filter, tile = outputs (2r, c), (2r+1, c);  AXIS 1: 1 x k filter, tile = outputs (r, 2c), (r, 2c+1)
+template <int KIND, int AXIS, int WM, int WN, int TN>
+__global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 72 && WM * WN <= 4) ? 3 : 2) void wino1d_kernel(Wino1Args a)
+{
+    using K = Wino1D<KIND>;
+    constexpr int NUV = K::NUV, WIN = K::WIN, STRIDE = K::STRIDE;
+    constexpr int NT = 64 * WM * WN, CKS = 4;
+    constexpr int BM = 16 * WM, NTILE = 16 * TN * WN;
+    constexpr int UNITS = TN / WM;                     // staging units (tile, channel) per thread: 4 * NTILE / NT
+    constexpr int TP = NTILE + ((NTILE & 31) ? 0 : 16);   // row pitch of T: the k = 0 / 1 halves of a 32-lane LDS access on different banks
+    constexpr int ASZ = NUV * CKS * BM, TSZ = NUV * CKS * TP;
+    constexpr int A4 = NUV * BM;                       // 16-byte chunks of the weight tile
+    constexpr int APER = (A4 + NT - 1) / NT;
+    static_assert(TN % WM == 0 && UNITS >= 1, "bad shape");
+    constexpr int OOB = 0x7ffffff0, NREC = 0x40000000;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // As[2][ASZ], Ts[2][TSZ], one dummy 16-byte slot per thread
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int zs = blockIdx.z;
+    unsigned bx, by;
+    xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    const int m0 = by * BM;
+    const int tyg = wdiv((int)bx, a.m_tilesx);
+    const int tx = (int)bx - tyg * a.tiles_x;
+    const int tgrp = wdiv(tyg, a.m_tilesy);
+    const int ty = tyg - tgrp * a.tiles_y;
+    const int n0 = tgrp * a.G;
+    const float *__restrict__ in0 = a.in + (long)n0 * a.in_n_stride;
+    const int ntile = a.G * a.TY * a.TX;
+    const int HW = a.H * a.W;
+
+    // ---- staging units: unit i of this thread = (tile q, channel k)
+    int goff[UNITS][WIN], tw[2][UNITS];
+    unsigned lastmask = 0;
+    const int last_c0 = (a.nsteps_total - 1) * CKS;
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+        const int w = tid + i * NT;
+        const int k = w / NTILE, q = w - k * NTILE;
+        const bool qv = q < ntile;
+        const int qc = qv ? q : 0;
+        const int g = wdiv(qc, a.m_tytx), rem = qc - g * (a.TY * a.TX);
+        const int r = ty * a.TY + wdiv(rem, a.m_tx), c = tx * a.TX + (rem - wdiv(rem, a.m_tx) * a.TX);   // tile-grid coordinates
+#pragma unroll
+        for (int e = 0; e < WIN; ++e) {
+            const int gy = AXIS == 0 ? 2 * STRIDE * r - a.pad + e : r;
+            const int gx = AXIS == 0 ? c : 2 * STRIDE * c - a.pad + e;
+            const bool ok = qv & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
+            goff[i][e] = ok ? 4 * (g * (int)a.in_n_stride + k * HW + gy * a.W + gx) : OOB;
+        }
+        tw[0][i] = 2 * ASZ + k * TP + q;
+        tw[1][i] = tw[0][i] + TSZ;
+        asm volatile("" : "+v"(tw[1][i]));
+        lastmask |= ((last_c0 + k < a.Cin) ? 1u : 0u) << i;
+    }
+    const bool mask_last = (a.Cin & 3) != 0;
+    // ---- weight loader: chunk f of the [e][channel block][k][16] tile <-> U[e][c0 + k][m0 + 16 blk + 4 c4 ..]
+    int aoff[APER], aw[2][APER];
+#pragma unroll
+    for (int i = 0; i < APER; ++i) {
+        const int f = tid + i * NT;
+        const bool fv = A4 % NT == 0 || f < A4;
+        const int c4 = f & 3, k = (f >> 2) & 3, blk = (f >> 4) % WM, e = f / (16 * WM);
+        aoff[i] = fv ? 4 * (int)(((long)e * a.Cin4 + k) * a.Mpad + m0 + blk * 16 + c4 * 4) : OOB;
+        aw[0][i] = fv ? f * 4 : 2 * ASZ + 2 * TSZ + tid * 4;
+        aw[1][i] = fv ? f * 4 + ASZ : 2 * ASZ + 2 * TSZ + tid * 4;
+    }
+    int ra[2], rt[2];
+    ra[0] = wm * 64 + lane;
+    ra[1] = ra[0] + ASZ;
+    rt[0] = 2 * ASZ + lk * TP + wn * (16 * TN) + l15;
+    rt[1] = rt[0] + TSZ;
+    asm volatile("" : "+v"(ra[1]));
+    asm volatile("" : "+v"(rt[1]));
+
+    floatx4 acc[TN][NUV];
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+        for (int e = 0; e < NUV; ++e) acc[tb][e] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    float preg[UNITS][WIN];
+    floatx4 areg[APER];
+    auto load_tiles = [&](int step) {
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * HW), 0, NREC, 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)step * CKS * a.Mpad), 0, NREC, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i)
+#pragma unroll
+            for (int e = 0; e < WIN; ++e) preg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][e], 0, 0));
+#pragma unroll
+        for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
+    };
+    auto transform_store = [&](int buf, int step) {
+        const bool last = mask_last && step == a.nsteps_total - 1;   // (uniform) channels past Cin become zeros
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            float t[NUV];
+            K::input(preg[i], t);
+            if (last) {
+                const bool dead = !((lastmask >> i) & 1u);
+#pragma unroll
+                for (int e = 0; e < NUV; ++e) t[e] = dead ? 0.0f : t[e];
+            }
+            float *T = smem + tw[buf][i];
+#pragma unroll
+            for (int e = 0; e < NUV; ++e) T[e * CKS * TP] = t[e];
+        }
+#pragma unroll
+        for (int i = 0; i < APER; ++i) *reinterpret_cast<floatx4 *>(smem + aw[buf][i]) = areg[i];
+    };
+    auto compute = [&](int buf) {
+        const float *A = smem + ra[buf];
+        const float *T = smem + rt[buf];
+#pragma unroll
+        for (int e = 0; e < NUV; ++e) {
+            const float af = A[e * (WM * 64)];
+#pragma unroll
+            for (int tb = 0; tb < TN; ++tb)
+                acc[tb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, T[e * CKS * TP + tb * 16], acc[tb][e], 0, 0, 0);
+        }
+    };
+
+    const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
+    const int s_begin = zs * per_slice;
+    const int nsteps = min(a.nsteps_total, s_begin + per_slice) - s_begin;
+    if (nsteps > 0) {
+        load_tiles(s_begin);
+        transform_store(0, s_begin);
+    }
+    __syncthreads();
+    {
+        int s = 0;
+        for (; s + 2 < nsteps; s += 2) {
+            load_tiles(s_begin + s + 1);
+            compute(0);
+            transform_store(1, s_begin + s + 1);
+            __syncthreads();
+            load_tiles(s_begin + s + 2);
+            compute(1);
+            transform_store(0, s_begin + s + 2);
+            __syncthreads();
+        }
+        if (s + 1 < nsteps) {
+            load_tiles(s_begin + s + 1);
+            compute(0);
+            transform_store(1, s_begin + s + 1);
+            __syncthreads();
+            compute(1);
+        } else if (nsteps > 0) {
+            compute(0);
+        }
+    }
+
+    // ---- epilogue: the two outputs of a tile from its NUV accumulators; lane = tile, registers = 4 consecutive channels
+    const long P = (long)a.N * a.Ho * a.Wo;
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int q = wn * (16 * TN) + tb * 16 + l15;
+        if (q >= ntile) continue;
+        const int g = wdiv(q, a.m_tytx), rem = q - g * (a.TY * a.TX);
+        const int r = ty * a.TY + wdiv(rem, a.m_tx), c = tx * a.TX + (rem - wdiv(rem, a.m_tx) * a.TX);
+        const int n = n0 + g;
+        const int y0 = AXIS == 0 ? 2 * r : r, x0 = AXIS == 0 ? c : 2 * c;
+        if (n >= a.N || y0 >= a.Ho || x0 >= a.Wo) continue;
+        const bool second = AXIS == 0 ? (y0 + 1 < a.Ho) : (x0 + 1 < a.Wo);
+        const long step2 = AXIS == 0 ? a.Wo : 1;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const int co = m0 + wm * 16 + 4 * lk + e4;
+            float m[NUV], o0, o1;
+#pragma unroll
+            for (int e = 0; e < NUV; ++e) m[e] = acc[tb][e][e4];
+            K::output(m, o0, o1);
+            if (a.ksplit > 1) {   // partial sums in output space, layout [slice][Mpad][P] (conv_splitk_reduce finishes)
+                float *__restrict__ ws = a.ws + ((long)zs * a.Mpad + co) * P + ((long)n * a.Ho + y0) * a.Wo + x0;
+                ws[0] = o0;
+                if (second) ws[step2] = o1;
+            } else if (co < a.Cout) {
+                const float b = a.bias[co];
+                float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)co * a.out_plane + (long)y0 * a.Wo + x0;
+                float v0 = o0 + b, v1 = o1 + b;
+                if (a.act) { v0 = fmaxf(v0, 0.1f * v0); v1 = fmaxf(v1, 0.1f * v1); }
+                if (AXIS == 1 && (a.Wo & 1) == 0) *reinterpret_cast<float2 *>(ob) = float2{v0, v1};
+                else { ob[0] = v0; if (second) ob[step2] = v1; }
+            }
+        }
+    }
+}
+
+// U[e][ci][co] = sum_t G[e][t] wp[t*Cin + ci][co]; rows ci >= Cin of U stay zero
+template <int KIND>
+__global__ __launch_bounds__(256) void wino1d_repack_kernel(float *__restrict__ wu, const float *__restrict__ wp, int Cin, int Cin4, int Mpad)
+{
+    using K = Wino1D<KIND>;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Cin * Mpad) return;
+    const int ci = (int)(idx / Mpad), co = (int)(idx - (long)ci * Mpad);
+    float w[K::TAPS];
+#pragma unroll
+    for (int t = 0; t < K::TAPS; ++t) w[t] = wp[((long)t * Cin + ci) * Mpad + co];
+#pragma unroll
+    for (int e = 0; e < K::NUV; ++e) {
+        float u = 0.0f;
+#pragma unroll
+        for (int t = 0; t < K::TAPS; ++t) u += K::g(e, t) * w[t];
+        wu[((long)e * Cin4 + ci) * Mpad + co] = u;
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 int wino_variant_tn(int v) { return v == 0 ? 2 : (v == 1 ? 4 : 3); }
 
@@ -734,6 +954,127 @@ void launch_wino_conv3(const Wino3Args &a, int variant, hipStream_t stream)
         case 2: hipLaunchKernelGGL((wino_conv3_kernel<4, 1>), grid, dim3(256), lds, stream, a); break;
         default: hipLaunchKernelGGL((wino_conv3_kernel<2, 2>), grid, dim3(256), lds, stream, a); break;
     }
+}
+
+
+// ---- 1-D host side
+// kinds: 0 = 3 taps stride 1, 1 / 2 / 3 = 5 / 7 / 9 taps stride 2.  variants: workgroup shapes (WM x WN waves, TN tile blocks per wave)
+int wino1d_kind(int taps, int stride)
+{
+    if (taps == 3 && stride == 1) return 0;
+    if (stride == 2 && (taps == 5 || taps == 7 || taps == 9)) return (taps - 3) / 2;
+    return -1;
+}
+int wino1d_nuv(int kind) { return kind == 0 ? 4 : 5 + 2 * kind; }
+struct W1Shape { int wm, wn, tn; };
+static const W1Shape kW1Shapes[WINO1D_VARIANTS] = {{2, 2, 2}, {4, 1, 4}, {2, 2, 4}, {4, 2, 4}};
+int wino1d_variant_bm(int v) { return 16 * kW1Shapes[v].wm; }
+int wino1d_variant_ntile(int v) { return 16 * kW1Shapes[v].tn * kW1Shapes[v].wn; }
+
+static size_t wino1d_lds_bytes(int kind, int v)
+{
+    const int nuv = wino1d_nuv(kind), bm = wino1d_variant_bm(v), ntile = wino1d_variant_ntile(v);
+    const int tp = ntile + ((ntile & 31) ? 0 : 16), nt = 64 * kW1Shapes[v].wm * kW1Shapes[v].wn;
+    return sizeof(float) * (2ul * (nuv * WINO_CKS * bm + nuv * WINO_CKS * tp) + 4ul * nt);
+}
+
+bool wino1d_variant_ok(int kind, int v)
+{
+    if (kind < 0 || v < 0 || v >= WINO1D_VARIANTS) return false;
+    // accumulators: NUV x TN x 4 registers per lane
+    return wino1d_nuv(kind) * kW1Shapes[v].tn * 4 <= 112 && wino1d_lds_bytes(kind, v) <= 160 * 1024;
+}
+
+// tile grid of one image: AXIS 0: (ceil(Ho/2), Wo), AXIS 1: (Ho, ceil(Wo/2)); workgroup tile = G images x TY x TX tiles
+bool wino1d_plan_geometry(Wino1Args &a, int kind, int variant, int axis, int n)
+{
+    if (!wino1d_variant_ok(kind, variant) || a.Mpad % wino1d_variant_bm(variant)) return false;
+    const int ntile = wino1d_variant_ntile(variant);
+    const int gh = axis == 0 ? (a.Ho + 1) / 2 : a.Ho, gw = axis == 0 ? a.Wo : (a.Wo + 1) / 2;
+    double best = 1e30;
+    bool ok = false;
+    for (int TX : {64, 32, 16, 8, gw}) {
+        if (TX > gw || TX < 1 || TX > ntile) continue;
+        int TY = ntile / TX;
+        if (TY < 1) continue;
+        if (TY > gh) TY = gh;
+        int G = 1;
+        if (TY == gh && TX == gw) { G = ntile / (TY * TX); if (G < 1) G = 1; if (G > n) G = n; }
+        const int tiles_y = (gh + TY - 1) / TY, tiles_x = (gw + TX - 1) / TX, groups = (n + G - 1) / G;
+        const double waste = (double)groups * tiles_y * tiles_x * ntile / ((double)n * gh * gw);
+        // rows of a workgroup tile share their input windows only along the filter axis: prefer tiles long in that direction
+        const double cost = waste * (1.0 + 0.01 * (axis == 0 ? TX : TY));
+        if (cost < best) {
+            best = cost;
+            ok = true;
+            a.G = G; a.TY = TY; a.TX = TX; a.tiles_y = tiles_y; a.tiles_x = tiles_x;
+        }
+    }
+    if (!ok) return false;
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    a.m_tytx = magic(a.TY * a.TX); a.m_tx = magic(a.TX); a.m_tilesx = magic(a.tiles_x); a.m_tilesy = magic(a.tiles_y);
+    return true;
+}
+
+long wino1d_workgroups(const Wino1Args &a, int variant)
+{
+    return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * (a.Mpad / wino1d_variant_bm(variant));
+}
+
+void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, hipStream_t s)
+{
+    const long total = (long)Cin * Mpad;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    switch (kind) {
+        case 0: hipLaunchKernelGGL(wino1d_repack_kernel<0>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad); break;
+        case 1: hipLaunchKernelGGL(wino1d_repack_kernel<1>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad); break;
+        case 2: hipLaunchKernelGGL(wino1d_repack_kernel<2>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad); break;
+        default: hipLaunchKernelGGL(wino1d_repack_kernel<3>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad); break;
+    }
+}
+
+template <int KIND, int AXIS, int WM, int WN, int TN>
+static void launch_w1(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    if constexpr (Wino1D<KIND>::NUV * TN * 4 <= 112) {
+        static bool configured = false;
+        if (!configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino1d_kernel<KIND, AXIS, WM, WN, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            configured = true;
+        }
+        hipLaunchKernelGGL((wino1d_kernel<KIND, AXIS, WM, WN, TN>), grid, dim3(64 * WM * WN), lds, s, a);
+    }
+}
+
+template <int KIND, int AXIS>
+static void launch_w1_variant(const Wino1Args &a, int variant, dim3 grid, size_t lds, hipStream_t s)
+{
+    switch (variant) {
+        case 0: launch_w1<KIND, AXIS, 2, 2, 2>(a, grid, lds, s); break;
+        case 1: launch_w1<KIND, AXIS, 4, 1, 4>(a, grid, lds, s); break;
+        case 2: launch_w1<KIND, AXIS, 2, 2, 4>(a, grid, lds, s); break;
+        default: launch_w1<KIND, AXIS, 4, 2, 4>(a, grid, lds, s); break;
+    }
+}
+
+void launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream)
+{
+    const int groups = (a.N + a.G - 1) / a.G;
+    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / wino1d_variant_bm(variant)), (unsigned)a.ksplit);
+    const size_t lds = wino1d_lds_bytes(kind, variant);
+#define W1_KIND(KK)                                                              \
+    case KK:                                                                     \
+        if (axis == 0) launch_w1_variant<KK, 0>(a, variant, grid, lds, stream);  \
+        else launch_w1_variant<KK, 1>(a, variant, grid, lds, stream);            \
+        break;
+    switch (kind) {
+        W1_KIND(0)
+        W1_KIND(1)
+        W1_KIND(2)
+        W1_KIND(3)
+        default: break;
+    }
+#undef W1_KIND
 }
 
 }  // namespace demon

@@ -62,6 +62,17 @@ struct Layer {
     float *d_wu = nullptr;
     mutable bool wu_dirty = true;
     int Cin4() const { return (Cin + 3) / 4 * 4; }
+    // 1-D minimal filtering (conv_wino.hip): k x 1 / 1 x k layers with 3 taps stride 1 or 5 / 7 / 9 taps stride 2; U[e][Cin4][Mpad] in d_w1
+    float *d_w1 = nullptr;
+    mutable bool w1_dirty = true;
+    int wino1d_axis() const { return kw == 1 ? 0 : 1; }
+    int wino1d_kind_of() const
+    {
+        if (kind != CONV || scale || Cin < 16 || (kh != 1 && kw != 1) || (kh == 1 && kw == 1)) return -1;
+        if (kw == 1 && sw != 1) return -1;
+        if (kh == 1 && sh != 1) return -1;
+        return wino1d_kind(kw == 1 ? kh : kw, kw == 1 ? sh : sw);
+    }
     bool wino3_shape() const { return kind == CONV && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && Cin >= 16 && !scale; }
     bool have_kernel = false, have_bias = false;
     std::vector<int64_t> kernel_dims;  // TF layout
@@ -262,6 +273,12 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
             if (z && hipMemset(z, 0, sizeof(float) * zf) == hipSuccess) L->zero = z;
         }
     }
+    if (L->wino1d_kind_of() >= 0 && !getenv("DEMON_NO_WINO")) {
+        const size_t nu = (size_t)wino1d_nuv(L->wino1d_kind_of()) * L->Cin4() * L->Mpad;
+        L->d_w1 = dev_alloc(c, sizeof(float) * nu);
+        if (!L->d_w1 || hipMemset(L->d_w1, 0, sizeof(float) * nu) != hipSuccess) return false;
+        L->w1_dirty = true;
+    }
     if (L->wino3_shape() && !getenv("DEMON_NO_WINO")) {
         const size_t nu = (size_t)16 * L->Cin4() * L->Mpad;
         L->d_wu = dev_alloc(c, sizeof(float) * nu);
@@ -330,6 +347,7 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
     L->have_kernel = true;
     L->wf_dirty = true;
     L->wu_dirty = true;
+    L->w1_dirty = true;
     return DEMON_OK;
 }
 
@@ -567,6 +585,10 @@ void run_small(const Layer *L, const ConvArgs &a, hipStream_t s)
 // for stand-alone layers
 void refresh_stream_weights(const Layer *L, hipStream_t s)
 {
+    if (L->d_w1 && L->w1_dirty) {   // transformed weights of the 1-D minimal-filtering kernel (conv_wino.hip)
+        launch_wino1d_repack(L->d_w1, L->d_wp, L->wino1d_kind_of(), L->Cin, L->Cin4(), L->Mpad, s);
+        L->w1_dirty = false;
+    }
     if (L->d_wu && L->wu_dirty) {   // transformed weights of the minimal-filtering 3 x 3 kernel (conv_wino.hip)
         launch_wino3_repack(L->d_wu, L->d_wp, L->Cin, L->Cin4(), L->Mpad, s);
         L->wu_dirty = false;
@@ -695,6 +717,40 @@ bool run_wino3(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipSt
     return true;
 }
 
+// 1-D minimal filtering for the k x 1 / 1 x k convs (conv_wino.hip), plan kind 10: variant = workgroup shape
+bool wino1d_applies(const Layer *L) { return L->d_w1 != nullptr && L->wino1d_kind_of() >= 0; }
+
+bool fill_wino1d_args(const Layer *L, const ConvArgs &a, int variant, Wino1Args &w)
+{
+    w.in = a.in; w.out = a.out; w.wu = L->d_w1; w.bias = a.bias; w.ws = a.ws;
+    w.N = a.N; w.Cin = L->Cin; w.Cin4 = L->Cin4(); w.H = a.H; w.W = a.W; w.Ho = a.Ho; w.Wo = a.Wo; w.in_n_stride = a.in_n_stride;
+    w.Cout = L->Cout; w.Mpad = L->Mpad; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
+    w.act = a.act; w.xcd = a.xcd;
+    w.pad = L->wino1d_axis() == 0 ? L->ph : L->pw;
+    w.nsteps_total = L->Cin4() / 4;
+    w.ksplit = 1;
+    return wino1d_plan_geometry(w, L->wino1d_kind_of(), variant, L->wino1d_axis(), a.N);
+}
+
+bool run_wino1d(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
+{
+    refresh_stream_weights(L, s);
+    Wino1Args w;
+    if (variant < 0 || variant >= WINO1D_VARIANTS || !fill_wino1d_args(L, a, variant, w)) return false;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > w.nsteps_total) ksplit = w.nsteps_total;
+    w.ksplit = ksplit;
+    launch_wino1d(w, L->wino1d_kind_of(), variant, L->wino1d_axis(), s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino1d<t%d,v%d>%s", L->wino1d_axis() == 0 ? L->kh : L->kw, variant, split_suffix(ksplit, false));
+    g_last_kernel = g_kernel_tag;
+    if (ksplit > 1) {
+        ConvArgs r = a;
+        r.ksplit = ksplit;
+        launch_splitk_reduce(r, L->ncls, s);
+    }
+    return true;
+}
+
 void run_mfma(const ConvArgs &a_in, ConvPlan plan, int ncls, hipStream_t s)
 {
     ConvArgs a = a_in;
@@ -732,6 +788,8 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                     run_frag(L, a, tile, clamp_split(ks), s);
                     return;
                 }
+            } else if (kind == 10) {
+                if (wino1d_applies(L) && run_wino1d(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 9) {
                 if (wino3_applies(L) && run_wino3(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 8) {
@@ -768,6 +826,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             }
             if (t.kind == 8 && wino_applies(L) && run_wino(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 9 && wino3_applies(L) && run_wino3(L, a, t.tile, clamp_split(t.ksplit), s)) return;
+            if (t.kind == 10 && wino1d_applies(L) && run_wino1d(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
                 const int tw = t.ksplit / 1000 - 1, ks = t.ksplit % 1000;
@@ -786,6 +845,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
         const int v = L->force_tile - 400;
         if (wino_applies(L) && v < WINO_VARIANTS && run_wino(L, a, v, clamp_split(L->force_split), s)) return;
         if (wino3_applies(L) && v < WINO3_VARIANTS && run_wino3(L, a, v, clamp_split(L->force_split), s)) return;
+        if (wino1d_applies(L) && v < WINO1D_VARIANTS && run_wino1d(L, a, v, clamp_split(L->force_split), s)) return;
     }
     if (L->force_tile >= 300 && L->force_tile < 400) {  // demon_bench_layer: fragment-tiled kernel variant force_tile - 300
         const int v = L->force_tile - 300;
@@ -878,6 +938,19 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
                 if (kw > 1 && (ks > 2 || nsteps < 4 * kw * ks)) continue;  // in-workgroup split-K is there to avoid the reduce launch
                 if (wgs * ks * kw < 96 || wgs * ks > 4096) continue;
                 cands.push_back({5, v, ks});
+            }
+        }
+    }
+    if (wino1d_applies(L)) {
+        const int nsteps = L->Cin4() / 4;
+        for (int v = 0; v < WINO1D_VARIANTS; ++v) {
+            Wino1Args w;
+            if (!fill_wino1d_args(L, a, v, w)) continue;
+            const long wgs = wino1d_workgroups(w, v);
+            for (int ks : {1, 2, 3, 4, 6, 8}) {
+                if (ks > 1 && (ks > nsteps / 8 || wgs * ks > 4096 || (long)ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
+                if (wgs * ks < 64) continue;
+                cands.push_back({10, v, ks});
             }
         }
     }
@@ -1960,7 +2033,7 @@ void slab_arrived(demon_ctx *c)
 {
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
-    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->wu_dirty = true; }
+    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->wu_dirty = true; L->w1_dirty = true; }
 }
 }  // namespace
 extern "C" {
@@ -2137,8 +2210,8 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
     if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
     // kinds: 0 im2col, 1 patch-staged, 3 small-Cout, 4 streaming, 5 fragment-tiled, 6 / 7 = kind 5 / 4 chained with the 1 x k partner
     // 8 = minimal-filtering transposed conv (conv_wino.hip)
-    if (kind < 0 || kind > 9 || kind == 2 || tile < 0 ||
-        tile >= (kind == 9 ? (int)WINO3_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
+    if (kind < 0 || kind > 10 || kind == 2 || tile < 0 ||
+        tile >= (kind == 10 ? (int)WINO1D_VARIANTS : kind == 9 ? (int)WINO3_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
@@ -2146,6 +2219,7 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             if (kind == 8 && !wino_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the minimal-filtering kernel applies to transposed convs only");
             if (kind == 9 && !wino3_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the F(2x2,3x3) kernel applies to 3 x 3 stride-1 convs only");
+            if (kind == 10 && !wino1d_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "no 1-D minimal-filtering form for this layer");
             if (kind == 4 && (!L->stream_ok() || L->Mpad % stream_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the streaming kernel does not apply to this layer");
             if (kind == 5 && (!L->stream_ok() || L->Mpad % frag_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the fragment-tiled kernel does not apply to this layer");
             if (kind == 6 || kind == 7) {

@@ -336,6 +336,33 @@ long wino3_workgroups(const Wino3Args &a, int variant);
 void launch_wino3_repack(float *wu, const float *wp, int Cin, int Cin4, int Mpad, hipStream_t s);
 void launch_wino_conv3(const Wino3Args &a, int variant, hipStream_t stream);
 
+// ---- 1-D minimal filtering for the k x 1 / 1 x k convs (conv_wino.hip, wino1d_tables.h) -------------------------------------------------
+struct Wino1Args {
+    const float *in;
+    float *out;
+    const float *wu;     // transformed weights U[e][Cin4][Mpad] (wino1d_repack_kernel)
+    const float *bias;
+    float *ws;           // split-K workspace [slice][Mpad][P], partial sums in OUTPUT space
+    int N, Cin, Cin4, H, W, Ho, Wo;
+    long in_n_stride;
+    int Cout, Mpad;
+    long out_n_stride, out_plane;
+    int act, ksplit, nsteps_total;       // K-steps of 4 input channels
+    int pad;                             // zeros in front of the first input sample along the filter axis
+    int G, TY, TX, tiles_y, tiles_x;     // workgroup tile = G images x TY x TX tiles (a tile = 2 outputs along the filter axis)
+    int xcd;
+    unsigned m_tytx, m_tx, m_tilesx, m_tilesy;
+};
+constexpr int WINO1D_VARIANTS = 4;   // (WM x WN waves, TN tile blocks): 2x2x2, 4x1x4, 2x2x4, 4x2x4
+int wino1d_kind(int taps, int stride);   // -1: no minimal-filtering form built for this filter
+int wino1d_nuv(int kind);
+int wino1d_variant_bm(int v);
+bool wino1d_variant_ok(int kind, int v);
+bool wino1d_plan_geometry(Wino1Args &a, int kind, int variant, int axis, int n);
+long wino1d_workgroups(const Wino1Args &a, int variant);
+void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, hipStream_t s);
+void launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream);
+
 // ---- tiny heads (conv_small.hip): VALU direct conv for Cout <= 4, fused motion tail -------------------------------------
 struct SmallConvArgs {
     const float *in;

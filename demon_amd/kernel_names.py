@@ -53,6 +53,17 @@ def kernel_tag(name):
             if p == params:
                 return "conv_frag<%dx%d,v%d>" % (32 * tm * wm, 32 * tn * wn, v)
         return "conv_frag<%dx%d,?>" % (32 * tm * wm, 32 * tn * wn)
+    m = re.search(r"wino_deconv_kernel<(\d+)", name)
+    if m:
+        return "wino_deconv<16x%d>" % (16 * int(m.group(1)))
+    m = re.search(r"wino_conv3_kernel<(\d+), (\d+)", name)
+    if m:
+        return "wino_conv3<%dx%d>" % (16 * int(m.group(1)), 32 * int(m.group(2)))
+    m = re.search(r"wino1d_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        kind, axis, wm, wn, tn = map(int, m.groups())
+        shapes = {(2, 2, 2): 0, (4, 1, 4): 1, (2, 2, 4): 2, (4, 2, 4): 3}
+        return "wino1d<t%d,v%d>" % (3 if kind == 0 else 3 + 2 * kind, shapes.get((wm, wn, tn), -1))
     m = re.search(r"deconv4_kernel<(\d+), (\d+), (\d+)", name)
     if m:
         bm, wm, wn = map(int, m.groups())
@@ -70,6 +81,12 @@ def rocprof_kernel_name(tag):
         return "demon::conv_mfma_kernel<%s, %s, ...>" % tuple(dims)
     if fam == "conv_patch" and len(dims) == 2:
         return "demon::conv_patch_kernel<%s, ...> (%sx%s tile, %s taps)" % (dims[0], dims[0], dims[1], rest.rstrip(">").split(",t")[-1])
+    if fam == "wino_deconv" and len(dims) == 2:
+        return "demon::wino_deconv_kernel<%d, ...> (16 channels x %s tiles per workgroup)" % (int(dims[1]) // 16, dims[1])
+    if fam == "wino_conv3" and len(dims) == 2:
+        return "demon::wino_conv3_kernel<%d, %d>" % (int(dims[0]) // 16, int(dims[1]) // 32)
+    if fam == "wino1d":
+        return "demon::wino1d_kernel<...> (%s)" % rest.rstrip(">")
     if fam == "deconv4":
         return "demon::deconv4_kernel<%s, ...>" % dims[0]
     if fam == "conv_stream" and len(dims) == 2:

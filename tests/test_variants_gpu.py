@@ -56,6 +56,7 @@ def test_all_variants_agree(gpu_ctx, layer):
     plans += [(0, t, ks) for t in range(8) for ks in (1002, 1005)] + [(4, v, 1003) for v in range(18)] + [(5, v, 1003) for v in range(22)]
     plans += [(8, v, ks) for v in range(3) for ks in (1, 2, 3)]   # minimal-filtering transposed conv (conv_wino.hip; Cin >= 16)
     plans += [(9, v, ks) for v in range(4) for ks in (1, 2)]      # F(2x2,3x3) (3 x 3 stride-1 convs, Cin >= 16)
+    plans += [(10, v, ks) for v in range(4) for ks in (1, 2)]     # 1-D minimal filtering (3 taps stride 1; 5 / 7 / 9 taps stride 2)
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
@@ -192,5 +193,43 @@ def test_minimal_filtering_conv3x3(gpu_ctx, shape):
                 assert err < 1e-5, "variant %d split %d: rel L1 %.3e" % (v, ks, err)
                 np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True))   # deterministic
         assert ran >= 6
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+# (cin, cout, kh, kw, sh, sw, H, W)
+WINO1D_LAYERS = [(64, 64, 3, 1, 1, 1, 24, 32), (128, 128, 1, 3, 1, 1, 12, 16), (64, 128, 5, 1, 2, 1, 48, 64), (128, 128, 1, 5, 1, 2, 24, 64),
+                 (32, 64, 7, 1, 2, 1, 24, 32), (32, 32, 1, 7, 1, 2, 12, 64), (32, 32, 1, 9, 1, 2, 12, 64), (16, 32, 9, 1, 2, 1, 48, 64),
+                 (18, 40, 3, 1, 1, 1, 7, 9), (30, 24, 1, 5, 1, 2, 5, 23), (20, 36, 7, 1, 2, 1, 17, 33), (256, 256, 3, 1, 1, 1, 12, 16), (34, 32, 1, 9, 1, 2, 9, 31)]
+
+
+@pytest.mark.parametrize("layer", WINO1D_LAYERS)
+def test_minimal_filtering_1d(gpu_ctx, layer):
+    """conv_wino.hip / wino1d_tables.h: two outputs along the filter axis per window with k + 1 (stride 1, k = 3) or k + 2 (stride 2,
+    polyphase F(2,re) + F(2,ro), k = 5 / 7 / 9) multiplications instead of 2k, for the k x 1 / 1 x k layers of convrelu2
+    (helpers.py:105-153).  Other rounding than the direct kernels (integer-valued transforms, denominators up to 24 in the output
+    transform; a CPU check of the generated tables in exact rationals is part of tools/gen_wino1d.py): the bar stays 1e-5 relative L1
+    against PyTorch, every workgroup shape and split-K, odd sizes, Cin not a multiple of 4"""
+    cin, cout, kh, kw, sh, sw, H, W = layer
+    rng = np.random.default_rng(34)
+    n = 5
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("conv", x, w, b, (sh, sw))
+    ran = 0
+    try:
+        for v in range(4):
+            for ks in (1, 2, 3):
+                os.environ["DEMON_FORCE_PLAN"] = "10,%d,%d" % (v, ks)
+                got = gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
+                tag = gpu_ctx.last_kernel()
+                if not tag.startswith("wino1d<"):
+                    continue   # shape not built for this filter (accumulator budget) or Cout not a multiple of its channel tile
+                ran += 1
+                err = rel_l1(got, want)
+                assert err < 1e-5, "variant %d split %d (%s): rel L1 %.3e" % (v, ks, tag, err)
+                np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True))   # deterministic
+        assert ran >= 3, ran
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)

@@ -16,10 +16,19 @@ CONV3 = [("rf conv1_1 64->64 96x128", 64, 96, 128, 64), ("rf conv2_1 128->128 48
          ("predict5 conv1 512->24 6x8", 512, 6, 8, 24)]
 
 
+CONV1D = [("conv2_1y 64->64 3x1 48x64", 64, 48, 64, 64, 3, 1, 1, 1), ("conv2_1x 64->64 1x3 48x64", 64, 48, 64, 64, 1, 3, 1, 1),
+          ("conv3_1y 128->128 3x1 24x32", 128, 24, 32, 128, 3, 1, 1, 1), ("conv4_1x 256->256 1x3 12x16", 256, 12, 16, 256, 1, 3, 1, 1),
+          ("conv5_1y 512->512 3x1 6x8", 512, 6, 8, 512, 3, 1, 1, 1),
+          ("conv3y 64->128 5x1 s2 48x64", 64, 48, 64, 128, 5, 1, 2, 1), ("conv3x 128->128 1x5 s2 24x64", 128, 24, 64, 128, 1, 5, 1, 2),
+          ("conv2y 32->32 7x1 s2 96x128", 32, 96, 128, 32, 7, 1, 2, 1), ("conv2x 32->32 1x7 s2 48x128", 32, 48, 128, 32, 1, 7, 1, 2),
+          ("conv1x 32->32 1x9 s2 96x256", 32, 96, 256, 32, 1, 9, 1, 2)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--skip-deconv", action="store_true")
+    ap.add_argument("--skip-conv3", action="store_true")
     args = ap.parse_args()
     ctx = DemonContext(0, 1)
     for lab, cin, h, w, cout in ([] if args.skip_deconv else LAYERS):
@@ -51,7 +60,7 @@ def main():
                 line += " | wino v%d %.3f ms %5.1f TF/s k%d [%s]" % (v, wb[0], wb[1], wb[2], " ".join(allks))
         print(line, flush=True)
     # 3 x 3 stride-1 convs: best direct plan (automatic choice and the patch tiles) vs F(2x2,3x3)
-    for lab, cin, h, w, cout in CONV3:
+    for lab, cin, h, w, cout in ([] if args.skip_conv3 else CONV3):
         line = "%-28s" % lab
         best = None
         for tile in (-1, 100, 101, 102, 103, 104, 106):
@@ -77,6 +86,33 @@ def main():
                     wb = (ms, tf, ks)
             if wb:
                 line += " | wino3 v%d %.3f ms %5.1f TF/s k%d [%s]" % (v, wb[0], wb[1], wb[2], " ".join(allks))
+        print(line, flush=True)
+    # separable layers: best direct plan vs 1-D minimal filtering
+    for lab, cin, h, w, cout, kh, kw, sh, sw in CONV1D:
+        line = "%-30s" % lab
+        best = None
+        cands = [(-1, 0)] + [(100 + t, 0) for t in range(6)] + [(300 + v, ks) for v in (0, 1, 2, 4, 6, 8, 9) for ks in (1, 2)]
+        for tile, ks in cands:
+            try:
+                ms, tf = ctx.bench_layer("conv", args.n, cin, h, w, cout, kh, kw, sh, sw, tile=tile, ksplit=ks, iters=10)
+            except Exception:
+                continue
+            if best is None or ms < best[0]:
+                best = (ms, tf, tile, ks)
+        line += " direct best %.3f ms %5.1f TF/s (t%d k%d)" % best
+        for v in range(4):
+            wb = None
+            for ks in (1, 2, 4):
+                try:
+                    ms, tf = ctx.bench_layer("conv", args.n, cin, h, w, cout, kh, kw, sh, sw, tile=400 + v, ksplit=ks, iters=10)
+                except Exception:
+                    continue
+                if not ctx.last_kernel().startswith("wino1d"):
+                    continue
+                if wb is None or ms < wb[0]:
+                    wb = (ms, tf, ks)
+            if wb:
+                line += " | w1d v%d %.3f ms %5.1f TF/s k%d" % (v, wb[0], wb[1], wb[2])
         print(line, flush=True)
     ctx.close()
 
