@@ -53,7 +53,10 @@ def build(force=False, verbose=False, extra_flags=(), tag=""):
         o = os.path.join(CSRC, src.replace(".hip", (".%s.o" % tag) if tag else ".o"))
         objs.append(o)
         if force or _needs_build(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + list(extra_flags) + ["-c", s, "-o", o])
+            # conv_wino.hip: the SLP vectoriser packs the +-1 transforms into v_pk_add_f32 plus register shuffles -- more VALU issue
+            # slots beside the fp32 MFMAs, which share the SIMD with the vector ALU
+            per_file = ["-fno-slp-vectorize"] if src == "conv_wino.hip" else []
+            jobs.append([hipcc] + FLAGS + per_file + list(extra_flags) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

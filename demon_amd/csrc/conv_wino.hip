@@ -354,7 +354,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
 // Wave = 16 channels x 32 tiles x 16 (u,v) = 32 accumulators of 4 registers; workgroup = WM channel blocks x WN tile groups, 4 waves.
 // Staging unit = (tile, channel, half): the rows u = 2 half, 2 half + 1 of Bt d B from 3 input rows x 4 columns (12 buffer loads with
 // out-of-range offsets for the zero padding, 16 VALU operations, 8 LDS stores); WN units per thread, `half` is uniform per wave.
-template <int WM, int WN>
+template <int WM, int WN, bool MASK>
 __global__ __launch_bounds__(64 * WM * WN, 2) void wino_conv3_kernel(Wino3Args a)
 {
     constexpr int NT = 64 * WM * WN, CKS = 4, TN = 2;
@@ -412,7 +412,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_conv3_kernel(Wino3Args a
         asm volatile("" : "+v"(tw[1][i]));
         lastmask |= ((last_c0 + k < a.Cin) ? 1u : 0u) << i;
     }
-    const bool mask_last = (a.Cin & 3) != 0;
     // ---- weight loader: chunk f = tid + i*NT of the [uv][channel block][k][16] tile <-> U[uv][c0 + k][m0 + 16 blk + 4 c4 ..]
     int aoff[APER];
 #pragma unroll
@@ -452,7 +451,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_conv3_kernel(Wino3Args a
     // `step`: the K-step the registers hold; in the last one the channels past Cin (they were read from whatever follows the input
     // in memory) are replaced by zeros
     auto transform_store = [&](int buf, int step) {
-        const bool last = mask_last && step == a.nsteps_total - 1;   // (uniform)
+        const bool last = MASK && step == a.nsteps_total - 1;   // (uniform)
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
             const float *l = preg[i];   // l[j*4 + c]: loaded row j (= input row half + j), column c
@@ -465,10 +464,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino_conv3_kernel(Wino3Args a
                 for (int c = 0; c < 4; ++c) { r0[c] = l[4 + c] - l[c]; r1[c] = l[c] - l[8 + c]; }
             }
             float t[8] = {r0[0] - r0[2], r0[1] + r0[2], r0[2] - r0[1], r0[1] - r0[3], r1[0] - r1[2], r1[1] + r1[2], r1[2] - r1[1], r1[1] - r1[3]};
-            if (last) {
-                const bool dead = !((lastmask >> i) & 1u);
+            if constexpr (MASK) {
+                if (last) {
+                    const bool dead = !((lastmask >> i) & 1u);
 #pragma unroll
-                for (int v = 0; v < 8; ++v) t[v] = dead ? 0.0f : t[v];
+                    for (int v = 0; v < 8; ++v) t[v] = dead ? 0.0f : t[v];
+                }
             }
             float *T = smem + tw[buf][i];
 #pragma unroll
@@ -602,7 +603,8 @@ __global__ __launch_bounds__(256) void wino3_repack_kernel(float *__restrict__ w
 // rationals).  Structure as wino_conv3_kernel: the threads of a workgroup transform every (tile, channel) window ONCE at staging time
 // and write the NUV values to LDS ([e][k][tile]); WM waves owning different 16-channel blocks read them as the MFMA B operand.
 //   AXIS 0: k x 1 filter, tile = outputs (2r, c), (2r+1, c);  AXIS 1: 1 x k filter, tile = outputs (r, 2c), (r, 2c+1)
-template <int KIND, int AXIS, int WM, int WN, int TN>
+// MASK: Cin is not a multiple of 4 -- the channels of the last K-step that do not exist are replaced by zeros (costs NUV selects per step)
+template <int KIND, int AXIS, int WM, int WN, int TN, bool MASK>
 __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 72 && WM * WN <= 4) ? 3 : 2) void wino1d_kernel(Wino1Args a)
 {
     using K = Wino1D<KIND>;
@@ -658,7 +660,6 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 72 && 
         asm volatile("" : "+v"(tw[1][i]));
         lastmask |= ((last_c0 + k < a.Cin) ? 1u : 0u) << i;
     }
-    const bool mask_last = (a.Cin & 3) != 0;
     // ---- weight loader: chunk f of the [e][channel block][k][16] tile <-> U[e][c0 + k][m0 + 16 blk + 4 c4 ..]
     int aoff[APER], aw[2][APER];
 #pragma unroll
@@ -697,15 +698,17 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 72 && 
         for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
     };
     auto transform_store = [&](int buf, int step) {
-        const bool last = mask_last && step == a.nsteps_total - 1;   // (uniform) channels past Cin become zeros
+        const bool last = MASK && step == a.nsteps_total - 1;   // (uniform) channels past Cin become zeros
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
             float t[NUV];
             K::input(preg[i], t);
-            if (last) {
-                const bool dead = !((lastmask >> i) & 1u);
+            if constexpr (MASK) {
+                if (last) {
+                    const bool dead = !((lastmask >> i) & 1u);
 #pragma unroll
-                for (int e = 0; e < NUV; ++e) t[e] = dead ? 0.0f : t[e];
+                    for (int e = 0; e < NUV; ++e) t[e] = dead ? 0.0f : t[e];
+                }
             }
             float *T = smem + tw[buf][i];
 #pragma unroll
@@ -757,37 +760,58 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 72 && 
         }
     }
 
-    // ---- epilogue: the two outputs of a tile from its NUV accumulators; lane = tile, registers = 4 consecutive channels
+    // ---- epilogue: the two outputs of a tile from its NUV accumulators; lane = tile, registers = 4 consecutive channels.
+    // Stores go through a buffer resource on this workgroup's corner of the output (uniform 64-bit base, 32-bit offsets per lane):
+    // channels past Cout, tiles past the image and padding lanes carry an out-of-range offset and are dropped by the hardware.
     const long P = (long)a.N * a.Ho * a.Wo;
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n0 * a.out_n_stride + (long)m0 * a.out_plane, 0, NREC, 0x00020000);
+    const int plane4 = 4 * (int)a.out_plane;
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
         const int q = wn * (16 * TN) + tb * 16 + l15;
-        if (q >= ntile) continue;
-        const int g = wdiv(q, a.m_tytx), rem = q - g * (a.TY * a.TX);
+        const bool qv = q < ntile;
+        const int qc = qv ? q : 0;
+        const int g = wdiv(qc, a.m_tytx), rem = qc - g * (a.TY * a.TX);
         const int r = ty * a.TY + wdiv(rem, a.m_tx), c = tx * a.TX + (rem - wdiv(rem, a.m_tx) * a.TX);
         const int n = n0 + g;
         const int y0 = AXIS == 0 ? 2 * r : r, x0 = AXIS == 0 ? c : 2 * c;
-        if (n >= a.N || y0 >= a.Ho || x0 >= a.Wo) continue;
+        const bool tv = qv && n < a.N && y0 < a.Ho && x0 < a.Wo;
         const bool second = AXIS == 0 ? (y0 + 1 < a.Ho) : (x0 + 1 < a.Wo);
-        const long step2 = AXIS == 0 ? a.Wo : 1;
+        const int step2 = AXIS == 0 ? a.Wo : 1;
+        const int toff = tv ? 4 * (g * (int)a.out_n_stride + y0 * a.Wo + x0) + (wm * 16 + 4 * lk) * plane4 : OOB;
+        if (a.ksplit > 1) {
+            if (!tv) continue;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {   // partial sums in output space, layout [slice][Mpad][P] (conv_splitk_reduce finishes)
+                const int co = m0 + wm * 16 + 4 * lk + e4;
+                float m[NUV], o0, o1;
+#pragma unroll
+                for (int e = 0; e < NUV; ++e) m[e] = acc[tb][e][e4];
+                K::output(m, o0, o1);
+                float *__restrict__ ws = a.ws + ((long)zs * a.Mpad + co) * P + ((long)n * a.Ho + y0) * a.Wo + x0;
+                ws[0] = o0;
+                if (second) ws[step2] = o1;
+            }
+            continue;
+        }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
-            const int co = m0 + wm * 16 + 4 * lk + e4;
+            const int col = wm * 16 + 4 * lk + e4;   // channel inside the workgroup's block
             float m[NUV], o0, o1;
 #pragma unroll
             for (int e = 0; e < NUV; ++e) m[e] = acc[tb][e][e4];
             K::output(m, o0, o1);
-            if (a.ksplit > 1) {   // partial sums in output space, layout [slice][Mpad][P] (conv_splitk_reduce finishes)
-                float *__restrict__ ws = a.ws + ((long)zs * a.Mpad + co) * P + ((long)n * a.Ho + y0) * a.Wo + x0;
-                ws[0] = o0;
-                if (second) ws[step2] = o1;
-            } else if (co < a.Cout) {
-                const float b = a.bias[co];
-                float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)co * a.out_plane + (long)y0 * a.Wo + x0;
-                float v0 = o0 + b, v1 = o1 + b;
-                if (a.act) { v0 = fmaxf(v0, 0.1f * v0); v1 = fmaxf(v1, 0.1f * v1); }
-                if (AXIS == 1 && (a.Wo & 1) == 0) *reinterpret_cast<float2 *>(ob) = float2{v0, v1};
-                else { ob[0] = v0; if (second) ob[step2] = v1; }
+            const float b = a.bias[m0 + col];   // (bias is padded to Mpad)
+            float v0 = o0 + b, v1 = o1 + b;
+            if (a.act) { v0 = fmaxf(v0, 0.1f * v0); v1 = fmaxf(v1, 0.1f * v1); }
+            const int off = (tv && m0 + col < a.Cout) ? toff + e4 * plane4 : OOB;
+            if (AXIS == 1 && (a.Wo & 1) == 0) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v0, v1}), orsrc, off, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), orsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), orsrc, (second && off != OOB) ? off + 4 * step2 : OOB, 0, 0);
             }
         }
     }
@@ -814,7 +838,7 @@ __global__ __launch_bounds__(256) void wino1d_repack_kernel(float *__restrict__ 
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
-int wino_variant_tn(int v) { return v == 0 ? 2 : (v == 1 ? 4 : 3); }
+int wino_variant_tn(int v) { return v == 0 ? 2 : (v == 1 ? 4 : (v == 2 ? 3 : 1)); }
 
 size_t wino_lds_bytes(const WinoArgs &a, int tn)
 {
@@ -880,6 +904,7 @@ void launch_wino_deconv(const WinoArgs &a, int variant, hipStream_t stream)
     switch (wino_variant_tn(variant)) {
         case 2: launch_wino_ept<2, 3>(a, grid, lds, stream); break;
         case 3: launch_wino_ept<3, 2>(a, grid, lds, stream); break;
+        case 1: launch_wino_ept<1, 4>(a, grid, lds, stream); break;
         default: launch_wino_ept<4, 2>(a, grid, lds, stream); break;
     }
 }
@@ -944,16 +969,22 @@ void launch_wino_conv3(const Wino3Args &a, int variant, hipStream_t stream)
     const size_t lds = wino3_lds_bytes(wm, wn);
     static bool configured = false;
     if (!configured) {   // 8-wave shapes need more than the default 64 KB of dynamic LDS
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(4, 2));
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(2, 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(4, 2));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(2, 4));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(4, 2));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<2, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(2, 4));
         configured = true;
     }
+#define W3_LAUNCH(WMM, WNN, THREADS)                                                                                         \
+    if (a.Cin & 3) hipLaunchKernelGGL((wino_conv3_kernel<WMM, WNN, true>), grid, dim3(THREADS), lds, stream, a);             \
+    else hipLaunchKernelGGL((wino_conv3_kernel<WMM, WNN, false>), grid, dim3(THREADS), lds, stream, a)
     switch (variant) {
-        case 0: hipLaunchKernelGGL((wino_conv3_kernel<4, 2>), grid, dim3(512), lds, stream, a); break;
-        case 1: hipLaunchKernelGGL((wino_conv3_kernel<2, 4>), grid, dim3(512), lds, stream, a); break;
-        case 2: hipLaunchKernelGGL((wino_conv3_kernel<4, 1>), grid, dim3(256), lds, stream, a); break;
-        default: hipLaunchKernelGGL((wino_conv3_kernel<2, 2>), grid, dim3(256), lds, stream, a); break;
+        case 0: W3_LAUNCH(4, 2, 512); break;
+        case 1: W3_LAUNCH(2, 4, 512); break;
+        case 2: W3_LAUNCH(4, 1, 256); break;
+        default: W3_LAUNCH(2, 2, 256); break;
     }
+#undef W3_LAUNCH
 }
 
 
@@ -1033,16 +1064,23 @@ void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin
     }
 }
 
+template <int KIND, int AXIS, int WM, int WN, int TN, bool MASK>
+static void launch_w1m(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino1d_kernel<KIND, AXIS, WM, WN, TN, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configured = true;
+    }
+    hipLaunchKernelGGL((wino1d_kernel<KIND, AXIS, WM, WN, TN, MASK>), grid, dim3(64 * WM * WN), lds, s, a);
+}
+
 template <int KIND, int AXIS, int WM, int WN, int TN>
 static void launch_w1(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
     if constexpr (Wino1D<KIND>::NUV * TN * 4 <= 112) {
-        static bool configured = false;
-        if (!configured) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino1d_kernel<KIND, AXIS, WM, WN, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            configured = true;
-        }
-        hipLaunchKernelGGL((wino1d_kernel<KIND, AXIS, WM, WN, TN>), grid, dim3(64 * WM * WN), lds, s, a);
+        if (a.Cin & 3) launch_w1m<KIND, AXIS, WM, WN, TN, true>(a, grid, lds, s);
+        else launch_w1m<KIND, AXIS, WM, WN, TN, false>(a, grid, lds, s);
     }
 }
 

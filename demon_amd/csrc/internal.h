@@ -306,7 +306,7 @@ struct WinoArgs {
     int xcd;
     unsigned m_plane, m_pw, m_tytx, m_tx, m_tilesx, m_tilesy;   // magic numbers for the prologue divisions
 };
-constexpr int WINO_VARIANTS = 3;   // tiles per workgroup: 32, 64, 48
+constexpr int WINO_VARIANTS = 4;   // tiles per workgroup: 32, 64, 48, 16
 int wino_variant_tn(int v);
 bool wino_plan_geometry(WinoArgs &a, int variant, int n);
 long wino_workgroups(const WinoArgs &a);

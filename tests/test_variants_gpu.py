@@ -54,7 +54,7 @@ def test_all_variants_agree(gpu_ctx, layer):
     plans += [(5, v, ks) for v in range(22) for ks in (1, 2, 3, 5)]    # fragment-tiled kernel (same requirement)
     # split-K combined inside the launch (ksplit + 1000: tickets instead of the reduce launch)
     plans += [(0, t, ks) for t in range(8) for ks in (1002, 1005)] + [(4, v, 1003) for v in range(18)] + [(5, v, 1003) for v in range(22)]
-    plans += [(8, v, ks) for v in range(3) for ks in (1, 2, 3)]   # minimal-filtering transposed conv (conv_wino.hip; Cin >= 16)
+    plans += [(8, v, ks) for v in range(4) for ks in (1, 2, 3)]   # minimal-filtering transposed conv (conv_wino.hip; Cin >= 16)
     plans += [(9, v, ks) for v in range(4) for ks in (1, 2)]      # F(2x2,3x3) (3 x 3 stride-1 convs, Cin >= 16)
     plans += [(10, v, ks) for v in range(4) for ks in (1, 2)]     # 1-D minimal filtering (3 taps stride 1; 5 / 7 / 9 taps stride 2)
     try:
@@ -146,12 +146,12 @@ def test_minimal_filtering_deconv(gpu_ctx, shape):
     try:
         os.environ["DEMON_FORCE_PLAN"] = "1,8,0"
         direct = gpu_ctx.deconv4x4s2(x, w, b, lrelu=True)
-        for v in range(3):
+        for v in range(4):
             for ks in (1, 2, 5):
                 os.environ["DEMON_FORCE_PLAN"] = "8,%d,%d" % (v, ks)
                 got = gpu_ctx.deconv4x4s2(x, w, b, lrelu=True)
                 tag = gpu_ctx.last_kernel()
-                assert tag.startswith("wino_deconv<16x%d>" % (32, 64, 48)[v]), tag
+                assert tag.startswith("wino_deconv<16x%d>" % (32, 64, 48, 16)[v]), tag
                 assert ("+splitk" in tag) == (ks > 1), tag
                 err = rel_l1(got, want)
                 assert err < 1e-5, "variant %d split %d: rel L1 %.3e" % (v, ks, err)

@@ -43,7 +43,7 @@ def main():
                 if best is None or ms < best[0]:
                     best = (ms, tf, tile, ks)
         line += " deconv4 best %.3f ms %5.1f TF/s (t%d k%d)" % best
-        for v in range(3):
+        for v in range(4):
             wb = None
             allks = []
             for ks in (1, 2, 3, 4, 6, 8):
