@@ -312,6 +312,10 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     }
     if (!wide) return;
     __syncthreads();
+    // stores through a buffer resource on this workgroup's corner of the output: uniform 64-bit base, one 32-bit offset per lane;
+    // padding lanes, rows past the image and channels past Cout carry an out-of-range offset (dropped by the hardware)
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n0 * a.out_n_stride + (long)m0 * plane, 0, 0x40000000, 0x00020000);
+    const int plane4 = 4 * (int)plane;
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
         const int q = tb * 16 + l15;
@@ -319,15 +323,12 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
         const int qc = qv ? q : 0;
         const int g = wdiv(qc, a.m_tytx), rem = qc - g * (a.TY * a.TX);
         const int r = wdiv(rem, a.m_tx), c = rem - r * a.TX;
-        const int n = n0 + g;
         const int ya = (ty * a.TY + r) * 2 + px, x0 = (tx * a.TX + c) * 2;   // this wave's class-grid row (a = px), first column
-        if (!(qv && n < a.N && ya < a.H && x0 < a.W)) continue;
-        float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)(2 * ya + py) * a.Wo + 2 * x0;
+        const bool tv = qv && n0 + g < a.N && ya < a.H && x0 < a.W;
+        const int toff = tv ? 4 * (g * (int)a.out_n_stride + (2 * ya + py) * a.Wo + 2 * x0) + 4 * lk * plane4 : 0x7ffffff0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int co = m0 + 4 * lk + e;
-            if (co >= a.Cout) continue;
-            const float b = a.bias[co];
+            const float b = a.bias[m0 + 4 * lk + e];   // (padded to Mpad)
             const float p0 = X[((((wave ^ 1) * TN + tb) * 4 + e) * 2 + 0) * 64 + lane], p1 = X[((((wave ^ 1) * TN + tb) * 4 + e) * 2 + 1) * 64 + lane];
             const float m0v = acc[tb][0][e], m1v = acc[tb][1][e];
             floatx4 v = px ? floatx4{p0, m0v, p1, m1v} : floatx4{m0v, p0, m1v, p1};
@@ -336,7 +337,8 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
                 v[i] += b;
                 if (a.act) v[i] = fmaxf(v[i], 0.1f * v[i]);   // == (v >= 0 ? v : 0.1 v)
             }
-            *reinterpret_cast<floatx4 *>(ob + (long)co * plane) = v;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, (tv && m0 + 4 * lk + e < a.Cout) ? toff + e * plane4 : 0x7ffffff0, 0, 0);
         }
     }
 }
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(256) void wino3_repack_kernel(float *__restrict__ w
 //   AXIS 0: k x 1 filter, tile = outputs (2r, c), (2r+1, c);  AXIS 1: 1 x k filter, tile = outputs (r, 2c), (r, 2c+1)
 // MASK: Cin is not a multiple of 4 -- the channels of the last K-step that do not exist are replaced by zeros (costs NUV selects per step)
 template <int KIND, int AXIS, int WM, int WN, int TN, bool MASK>
-__global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 72 && WM * WN <= 4) ? 3 : 2) void wino1d_kernel(Wino1Args a)
+__global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 64 && WM * WN <= 4) ? 3 : 2) void wino1d_kernel(Wino1Args a)
 {
     using K = Wino1D<KIND>;
     constexpr int NUV = K::NUV, WIN = K::WIN, STRIDE = K::STRIDE;
@@ -685,9 +687,11 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 72 && 
 #pragma unroll
         for (int e = 0; e < NUV; ++e) acc[tb][e] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    float preg[UNITS][WIN];
-    floatx4 areg[APER];
-    auto load_tiles = [&](int step) {
+    // global loads run TWO K-steps ahead (two register sets): step s on buffer s&1:
+    //   loads of step s+2 | MFMAs of step s | transform + LDS stores of step s+1 (loaded during step s-1) | barrier
+    float pregA[UNITS][WIN], pregB[UNITS][WIN];
+    floatx4 aregA[APER], aregB[APER];
+    auto load_tiles = [&](float (&preg)[UNITS][WIN], floatx4 (&areg)[APER], int step) {
         const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * HW), 0, NREC, 0x00020000);
         const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)step * CKS * a.Mpad), 0, NREC, 0x00020000);
 #pragma unroll
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 72 && 
 #pragma unroll
         for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
     };
-    auto transform_store = [&](int buf, int step) {
+    auto transform_store = [&](const float (&preg)[UNITS][WIN], const floatx4 (&areg)[APER], int buf, int step) {
         const bool last = MASK && step == a.nsteps_total - 1;   // (uniform) channels past Cin become zeros
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
@@ -732,27 +736,28 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 72 && 
     const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
     const int s_begin = zs * per_slice;
     const int nsteps = min(a.nsteps_total, s_begin + per_slice) - s_begin;
+    auto phys = [&](int x) { return s_begin + min(x, nsteps - 1); };   // a run-ahead past the end of the slice re-reads its last step
     if (nsteps > 0) {
-        load_tiles(s_begin);
-        transform_store(0, s_begin);
+        load_tiles(pregA, aregA, phys(0));
+        load_tiles(pregB, aregB, phys(1));
+        transform_store(pregA, aregA, 0, phys(0));
     }
     __syncthreads();
     {
         int s = 0;
         for (; s + 2 < nsteps; s += 2) {
-            load_tiles(s_begin + s + 1);
+            load_tiles(pregA, aregA, phys(s + 2));
             compute(0);
-            transform_store(1, s_begin + s + 1);
+            transform_store(pregB, aregB, 1, phys(s + 1));
             __syncthreads();
-            load_tiles(s_begin + s + 2);
+            load_tiles(pregB, aregB, phys(s + 3));
             compute(1);
-            transform_store(0, s_begin + s + 2);
+            transform_store(pregA, aregA, 0, phys(s + 2));
             __syncthreads();
         }
         if (s + 1 < nsteps) {
-            load_tiles(s_begin + s + 1);
             compute(0);
-            transform_store(1, s_begin + s + 1);
+            transform_store(pregB, aregB, 1, phys(s + 1));
             __syncthreads();
             compute(1);
         } else if (nsteps > 0) {
