@@ -163,7 +163,8 @@ def emit_input(BT, win, tag):
 KINDS = [(3, 1), (5, 2), (7, 2), (9, 2)]
 
 
-def main():
+def render():
+    """the text of wino1d_tables.h (every matrix checked in exact rationals on the way)"""
     out = ["// wino1d_tables.h -- GENERATED by tools/gen_wino1d.py (do not edit): transforms of the 1-D minimal-filtering convolutions",
            "// of conv_wino.hip.  kind 0: 3 taps stride 1 (F(2,3)); kinds 1 / 2 / 3: 5 / 7 / 9 taps stride 2 (polyphase F(2,re) + F(2,ro)).",
            "#pragma once", "", "namespace demon {", "",
@@ -194,10 +195,17 @@ def main():
         out.append("};")
         out.append("")
     out.append("}  // namespace demon")
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "demon_amd", "csrc", "wino1d_tables.h")
-    with open(path, "w") as f:
-        f.write("\n".join(out) + "\n")
-    print("wrote", os.path.normpath(path))
+    return "\n".join(out) + "\n"
+
+
+HEADER = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "demon_amd", "csrc", "wino1d_tables.h"))
+
+
+def main():
+    text = render()
+    with open(HEADER, "w") as f:
+        f.write(text)
+    print("wrote", HEADER)
 
 
 if __name__ == "__main__":
