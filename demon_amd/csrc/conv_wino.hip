@@ -605,18 +605,19 @@ __global__ __launch_bounds__(256) void wino3_repack_kernel(float *__restrict__ w
 // rationals).  Structure as wino_conv3_kernel: the threads of a workgroup transform every (tile, channel) window ONCE at staging time
 // and write the NUV values to LDS ([e][k][tile]); WM waves owning different 16-channel blocks read them as the MFMA B operand.
 //   AXIS 0: k x 1 filter, tile = outputs (2r, c), (2r+1, c);  AXIS 1: 1 x k filter, tile = outputs (r, 2c), (r, 2c+1)
-// MASK: Cin is not a multiple of 4 -- the channels of the last K-step that do not exist are replaced by zeros (costs NUV selects per step)
-template <int KIND, int AXIS, int WM, int WN, int TN, bool MASK>
-__global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 64 && WM * WN <= 4) ? 3 : 2) void wino1d_kernel(Wino1Args a)
+// KG: MFMA K groups (of 4 input channels) per K-step, i.e. per barrier.  MASK: Cin is not a multiple of 4 KG -- the channels of the
+// last K-step that do not exist are replaced by zeros (costs NUV selects per step)
+template <int KIND, int AXIS, int WM, int WN, int TN, int KG, bool MASK>
+__global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG == 1 ? 64 : 32) && WM * WN <= 4) ? 3 : 2) void wino1d_kernel(Wino1Args a)
 {
     using K = Wino1D<KIND>;
     constexpr int NUV = K::NUV, WIN = K::WIN, STRIDE = K::STRIDE;
-    constexpr int NT = 64 * WM * WN, CKS = 4;
+    constexpr int NT = 64 * WM * WN, CKS = 4 * KG;
     constexpr int BM = 16 * WM, NTILE = 16 * TN * WN;
-    constexpr int UNITS = TN / WM;                     // staging units (tile, channel) per thread: 4 * NTILE / NT
+    constexpr int UNITS = KG * TN / WM;                // staging units (tile, channel) per thread: CKS * NTILE / NT
     constexpr int TP = NTILE + ((NTILE & 31) ? 0 : 16);   // row pitch of T: the k = 0 / 1 halves of a 32-lane LDS access on different banks
     constexpr int ASZ = NUV * CKS * BM, TSZ = NUV * CKS * TP;
-    constexpr int A4 = NUV * BM;                       // 16-byte chunks of the weight tile
+    constexpr int A4 = NUV * BM * KG;                  // 16-byte chunks of the weight tile
     constexpr int APER = (A4 + NT - 1) / NT;
     static_assert(TN % WM == 0 && UNITS >= 1, "bad shape");
     constexpr int OOB = 0x7ffffff0, NREC = 0x40000000;
@@ -668,13 +669,13 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 64 && 
     for (int i = 0; i < APER; ++i) {
         const int f = tid + i * NT;
         const bool fv = A4 % NT == 0 || f < A4;
-        const int c4 = f & 3, k = (f >> 2) & 3, blk = (f >> 4) % WM, e = f / (16 * WM);
+        const int c4 = f & 3, k = (f >> 2) % CKS, blk = (f / (4 * CKS)) % WM, e = f / (4 * CKS * WM);
         aoff[i] = fv ? 4 * (int)(((long)e * a.Cin4 + k) * a.Mpad + m0 + blk * 16 + c4 * 4) : OOB;
         aw[0][i] = fv ? f * 4 : 2 * ASZ + 2 * TSZ + tid * 4;
         aw[1][i] = fv ? f * 4 + ASZ : 2 * ASZ + 2 * TSZ + tid * 4;
     }
     int ra[2], rt[2];
-    ra[0] = wm * 64 + lane;
+    ra[0] = wm * (16 * CKS) + lane;
     ra[1] = ra[0] + ASZ;
     rt[0] = 2 * ASZ + lk * TP + wn * (16 * TN) + l15;
     rt[1] = rt[0] + TSZ;
@@ -725,12 +726,14 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= 64 && 
         const float *A = smem + ra[buf];
         const float *T = smem + rt[buf];
 #pragma unroll
-        for (int e = 0; e < NUV; ++e) {
-            const float af = A[e * (WM * 64)];
+        for (int kg = 0; kg < KG; ++kg)
 #pragma unroll
-            for (int tb = 0; tb < TN; ++tb)
-                acc[tb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, T[e * CKS * TP + tb * 16], acc[tb][e], 0, 0, 0);
-        }
+            for (int e = 0; e < NUV; ++e) {
+                const float af = A[e * (WM * 16 * CKS) + kg * 64];
+#pragma unroll
+                for (int tb = 0; tb < TN; ++tb)
+                    acc[tb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, T[(e * CKS + kg * 4) * TP + tb * 16], acc[tb][e], 0, 0, 0);
+            }
     };
 
     const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
@@ -1003,21 +1006,23 @@ int wino1d_kind(int taps, int stride)
 }
 int wino1d_nuv(int kind) { return kind == 0 ? 4 : 5 + 2 * kind; }
 struct W1Shape { int wm, wn, tn; };
-static const W1Shape kW1Shapes[WINO1D_VARIANTS] = {{2, 2, 2}, {4, 1, 4}, {2, 2, 4}, {4, 2, 4}};
+static const W1Shape kW1Shapes[WINO1D_VARIANTS] = {{2, 2, 2}, {4, 1, 4}, {2, 2, 4}, {4, 2, 4}, {2, 2, 2}, {4, 1, 4}, {2, 2, 4}, {4, 2, 4}};
+int wino1d_variant_kg(int v) { return v >= 4 ? 2 : 1; }
 int wino1d_variant_bm(int v) { return 16 * kW1Shapes[v].wm; }
 int wino1d_variant_ntile(int v) { return 16 * kW1Shapes[v].tn * kW1Shapes[v].wn; }
 
 static size_t wino1d_lds_bytes(int kind, int v)
 {
     const int nuv = wino1d_nuv(kind), bm = wino1d_variant_bm(v), ntile = wino1d_variant_ntile(v);
-    const int tp = ntile + ((ntile & 31) ? 0 : 16), nt = 64 * kW1Shapes[v].wm * kW1Shapes[v].wn;
-    return sizeof(float) * (2ul * (nuv * WINO_CKS * bm + nuv * WINO_CKS * tp) + 4ul * nt);
+    const int tp = ntile + ((ntile & 31) ? 0 : 16), nt = 64 * kW1Shapes[v].wm * kW1Shapes[v].wn, cks = 4 * wino1d_variant_kg(v);
+    return sizeof(float) * (2ul * (nuv * cks * bm + nuv * cks * tp) + 4ul * nt);
 }
 
 bool wino1d_variant_ok(int kind, int v)
 {
     if (kind < 0 || v < 0 || v >= WINO1D_VARIANTS) return false;
-    // accumulators: NUV x TN x 4 registers per lane
+    // accumulators: NUV x TN x 4 registers per lane; two K groups per step (variants 4..7) double the staging registers: kinds 0 / 1 only
+    if (wino1d_variant_kg(v) == 2 && (kind > 1 || (kind == 1 && kW1Shapes[v].tn > 2))) return false;   // (register budget)
     return wino1d_nuv(kind) * kW1Shapes[v].tn * 4 <= 112 && wino1d_lds_bytes(kind, v) <= 160 * 1024;
 }
 
@@ -1069,23 +1074,23 @@ void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin
     }
 }
 
-template <int KIND, int AXIS, int WM, int WN, int TN, bool MASK>
+template <int KIND, int AXIS, int WM, int WN, int TN, int KG, bool MASK>
 static void launch_w1m(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino1d_kernel<KIND, AXIS, WM, WN, TN, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino1d_kernel<KIND, AXIS, WM, WN, TN, KG, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         configured = true;
     }
-    hipLaunchKernelGGL((wino1d_kernel<KIND, AXIS, WM, WN, TN, MASK>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((wino1d_kernel<KIND, AXIS, WM, WN, TN, KG, MASK>), grid, dim3(64 * WM * WN), lds, s, a);
 }
 
-template <int KIND, int AXIS, int WM, int WN, int TN>
+template <int KIND, int AXIS, int WM, int WN, int TN, int KG>
 static void launch_w1(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    if constexpr (Wino1D<KIND>::NUV * TN * 4 <= 112) {
-        if (a.Cin & 3) launch_w1m<KIND, AXIS, WM, WN, TN, true>(a, grid, lds, s);
-        else launch_w1m<KIND, AXIS, WM, WN, TN, false>(a, grid, lds, s);
+    if constexpr (Wino1D<KIND>::NUV * TN * 4 <= 112 && (KG == 1 || KIND == 0 || (KIND == 1 && TN <= 2))) {
+        if (a.Cin % (4 * KG)) launch_w1m<KIND, AXIS, WM, WN, TN, KG, true>(a, grid, lds, s);
+        else launch_w1m<KIND, AXIS, WM, WN, TN, KG, false>(a, grid, lds, s);
     }
 }
 
@@ -1093,10 +1098,14 @@ template <int KIND, int AXIS>
 static void launch_w1_variant(const Wino1Args &a, int variant, dim3 grid, size_t lds, hipStream_t s)
 {
     switch (variant) {
-        case 0: launch_w1<KIND, AXIS, 2, 2, 2>(a, grid, lds, s); break;
-        case 1: launch_w1<KIND, AXIS, 4, 1, 4>(a, grid, lds, s); break;
-        case 2: launch_w1<KIND, AXIS, 2, 2, 4>(a, grid, lds, s); break;
-        default: launch_w1<KIND, AXIS, 4, 2, 4>(a, grid, lds, s); break;
+        case 0: launch_w1<KIND, AXIS, 2, 2, 2, 1>(a, grid, lds, s); break;
+        case 1: launch_w1<KIND, AXIS, 4, 1, 4, 1>(a, grid, lds, s); break;
+        case 2: launch_w1<KIND, AXIS, 2, 2, 4, 1>(a, grid, lds, s); break;
+        case 3: launch_w1<KIND, AXIS, 4, 2, 4, 1>(a, grid, lds, s); break;
+        case 4: launch_w1<KIND, AXIS, 2, 2, 2, 2>(a, grid, lds, s); break;
+        case 5: launch_w1<KIND, AXIS, 4, 1, 4, 2>(a, grid, lds, s); break;
+        case 6: launch_w1<KIND, AXIS, 2, 2, 4, 2>(a, grid, lds, s); break;
+        default: launch_w1<KIND, AXIS, 4, 2, 4, 2>(a, grid, lds, s); break;
     }
 }
 

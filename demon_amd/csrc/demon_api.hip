@@ -274,7 +274,7 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
         }
     }
     if (L->wino1d_kind_of() >= 0 && !getenv("DEMON_NO_WINO")) {
-        const size_t nu = (size_t)wino1d_nuv(L->wino1d_kind_of()) * L->Cin4() * L->Mpad;
+        const size_t nu = ((size_t)wino1d_nuv(L->wino1d_kind_of()) * L->Cin4() + 8) * L->Mpad;   // + 8 rows: the two-K-group variants read (and multiply by zeros) up to 4 rows past the end
         L->d_w1 = dev_alloc(c, sizeof(float) * nu);
         if (!L->d_w1 || hipMemset(L->d_w1, 0, sizeof(float) * nu) != hipSuccess) return false;
         L->w1_dirty = true;
@@ -727,7 +727,8 @@ bool fill_wino1d_args(const Layer *L, const ConvArgs &a, int variant, Wino1Args 
     w.Cout = L->Cout; w.Mpad = L->Mpad; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
     w.act = a.act; w.xcd = a.xcd;
     w.pad = L->wino1d_axis() == 0 ? L->ph : L->pw;
-    w.nsteps_total = L->Cin4() / 4;
+    const int cks = 4 * wino1d_variant_kg(variant);
+    w.nsteps_total = (L->Cin + cks - 1) / cks;
     w.ksplit = 1;
     return wino1d_plan_geometry(w, L->wino1d_kind_of(), variant, L->wino1d_axis(), a.N);
 }
@@ -942,10 +943,10 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
         }
     }
     if (wino1d_applies(L)) {
-        const int nsteps = L->Cin4() / 4;
         for (int v = 0; v < WINO1D_VARIANTS; ++v) {
             Wino1Args w;
             if (!fill_wino1d_args(L, a, v, w)) continue;
+            const int nsteps = w.nsteps_total * wino1d_variant_kg(v);
             const long wgs = wino1d_workgroups(w, v);
             for (int ks : {1, 2, 3, 4, 6, 8}) {
                 if (ks > 1 && (ks > nsteps / 8 || wgs * ks > 4096 || (long)ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
@@ -2628,7 +2629,7 @@ int demon_last_kernel(char *tag, int tag_cap)
 int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw,
                       int tile, int ksplit, int iters, float *avg_ms, double *flops)
 {
-    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || (tile >= 200 + STREAM_VARIANTS && tile < 300) || (tile >= 300 + FRAG_VARIANTS && tile < 400) || tile >= 400 + WINO3_VARIANTS) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || (tile >= 200 + STREAM_VARIANTS && tile < 300) || (tile >= 300 + FRAG_VARIANTS && tile < 400) || tile >= 400 + WINO1D_VARIANTS) return fail(c, DEMON_ERR_INVALID, "bad argument");
     hipSetDevice(c->device);
     demon_ctx scratch;
     scratch.device = c->device;

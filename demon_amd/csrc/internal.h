@@ -353,7 +353,8 @@ struct Wino1Args {
     int xcd;
     unsigned m_tytx, m_tx, m_tilesx, m_tilesy;
 };
-constexpr int WINO1D_VARIANTS = 4;   // (WM x WN waves, TN tile blocks): 2x2x2, 4x1x4, 2x2x4, 4x2x4
+constexpr int WINO1D_VARIANTS = 8;   // (WM x WN waves, TN tile blocks): 2x2x2, 4x1x4, 2x2x4, 4x2x4 with one (0..3) or two (4..7) K groups per step
+int wino1d_variant_kg(int v);
 int wino1d_kind(int taps, int stride);   // -1: no minimal-filtering form built for this filter
 int wino1d_nuv(int kind);
 int wino1d_variant_bm(int v);

@@ -100,7 +100,7 @@ def main():
             if best is None or ms < best[0]:
                 best = (ms, tf, tile, ks)
         line += " direct best %.3f ms %5.1f TF/s (t%d k%d)" % best
-        for v in range(4):
+        for v in range(8):
             wb = None
             for ks in (1, 2, 4):
                 try:
