@@ -639,10 +639,11 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     const int ntile = a.G * a.TY * a.TX;
     const int HW = a.H * a.W;
 
-    // ---- staging units: unit i of this thread = (tile q, channel k)
-    int goff[UNITS][WIN], tw[2][UNITS];
+    // ---- staging units: unit i of this thread = (tile q, channel k).  a.cross > 1 (3 x 3 layers as three 1 x 3 filters whose products
+    // add up in the same accumulators): the K-steps run over (cross tap ky, channel step); the load offsets are set per ky
+    int goff[UNITS][WIN], tw[2][UNITS], ur[UNITS], uc[UNITS], ub[UNITS];
     unsigned lastmask = 0;
-    const int last_c0 = (a.nsteps_total - 1) * CKS;
+    const int last_c0 = (a.csteps - 1) * CKS;
 #pragma unroll
     for (int i = 0; i < UNITS; ++i) {
         const int w = tid + i * NT;
@@ -650,19 +651,27 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
         const bool qv = q < ntile;
         const int qc = qv ? q : 0;
         const int g = wdiv(qc, a.m_tytx), rem = qc - g * (a.TY * a.TX);
-        const int r = ty * a.TY + wdiv(rem, a.m_tx), c = tx * a.TX + (rem - wdiv(rem, a.m_tx) * a.TX);   // tile-grid coordinates
-#pragma unroll
-        for (int e = 0; e < WIN; ++e) {
-            const int gy = AXIS == 0 ? 2 * STRIDE * r - a.pad + e : r;
-            const int gx = AXIS == 0 ? c : 2 * STRIDE * c - a.pad + e;
-            const bool ok = qv & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
-            goff[i][e] = ok ? 4 * (g * (int)a.in_n_stride + k * HW + gy * a.W + gx) : OOB;
-        }
+        ur[i] = ty * a.TY + wdiv(rem, a.m_tx);                       // tile-grid coordinates
+        uc[i] = tx * a.TX + (rem - wdiv(rem, a.m_tx) * a.TX);
+        ub[i] = (qv && n0 + g < a.N) ? 4 * (g * (int)a.in_n_stride + k * HW) : -1;   // byte offset of the unit's channel plane, -1: no such tile
         tw[0][i] = 2 * ASZ + k * TP + q;
         tw[1][i] = tw[0][i] + TSZ;
         asm volatile("" : "+v"(tw[1][i]));
         lastmask |= ((last_c0 + k < a.Cin) ? 1u : 0u) << i;
     }
+    auto set_offsets = [&](int ky) {
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i)
+#pragma unroll
+            for (int e = 0; e < WIN; ++e) {
+                const int gy = AXIS == 0 ? 2 * STRIDE * ur[i] - a.pad + e : ur[i] + ky - a.cross_pad;
+                const int gx = AXIS == 0 ? uc[i] + ky - a.cross_pad : 2 * STRIDE * uc[i] - a.pad + e;
+                const bool ok = (ub[i] >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
+                goff[i][e] = ok ? ub[i] + 4 * (gy * a.W + gx) : OOB;
+            }
+    };
+    set_offsets(0);
+    int cur_ky = 0;
     // ---- weight loader: chunk f of the [e][channel block][k][16] tile <-> U[e][c0 + k][m0 + 16 blk + 4 c4 ..]
     int aoff[APER], aw[2][APER];
 #pragma unroll
@@ -693,8 +702,14 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     float pregA[UNITS][WIN], pregB[UNITS][WIN];
     floatx4 aregA[APER], aregB[APER];
     auto load_tiles = [&](float (&preg)[UNITS][WIN], floatx4 (&areg)[APER], int step) {
-        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * HW), 0, NREC, 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)step * CKS * a.Mpad), 0, NREC, 0x00020000);
+        int ky = 0, cs = step;
+        if (a.cross > 1) {   // (uniform) steps are issued in increasing order: the offsets change twice per kernel
+            ky = step / a.csteps;
+            cs = step - ky * a.csteps;
+            if (ky != cur_ky) { set_offsets(ky); cur_ky = ky; }
+        }
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, NREC, 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + ((long)ky * NUV * a.Cin4 + (long)cs * CKS) * a.Mpad), 0, NREC, 0x00020000);
 #pragma unroll
         for (int i = 0; i < UNITS; ++i)
 #pragma unroll
@@ -703,7 +718,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
         for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
     };
     auto transform_store = [&](const float (&preg)[UNITS][WIN], const floatx4 (&areg)[APER], int buf, int step) {
-        const bool last = MASK && step == a.nsteps_total - 1;   // (uniform) channels past Cin become zeros
+        const bool last = MASK && (step % a.csteps) == a.csteps - 1;   // (uniform) channels past Cin become zeros
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
             float t[NUV];
@@ -825,23 +840,26 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     }
 }
 
-// U[e][ci][co] = sum_t G[e][t] wp[t*Cin + ci][co]; rows ci >= Cin of U stay zero
+// U[ky][e][ci][co] = sum_t G[e][t] wp[(ky*TAPS + t)*Cin + ci][co] (cross = 1: plain k x 1 / 1 x k layers; cross = 3: the rows of a
+// 3 x 3 kernel as three 1 x 3 filters); rows ci >= Cin of U stay zero
 template <int KIND>
-__global__ __launch_bounds__(256) void wino1d_repack_kernel(float *__restrict__ wu, const float *__restrict__ wp, int Cin, int Cin4, int Mpad)
+__global__ __launch_bounds__(256) void wino1d_repack_kernel(float *__restrict__ wu, const float *__restrict__ wp, int Cin, int Cin4, int Mpad, int cross)
 {
     using K = Wino1D<KIND>;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)Cin * Mpad) return;
     const int ci = (int)(idx / Mpad), co = (int)(idx - (long)ci * Mpad);
-    float w[K::TAPS];
+    for (int ky = 0; ky < cross; ++ky) {
+        float w[K::TAPS];
 #pragma unroll
-    for (int t = 0; t < K::TAPS; ++t) w[t] = wp[((long)t * Cin + ci) * Mpad + co];
+        for (int t = 0; t < K::TAPS; ++t) w[t] = wp[((long)(ky * K::TAPS + t) * Cin + ci) * Mpad + co];
 #pragma unroll
-    for (int e = 0; e < K::NUV; ++e) {
-        float u = 0.0f;
+        for (int e = 0; e < K::NUV; ++e) {
+            float u = 0.0f;
 #pragma unroll
-        for (int t = 0; t < K::TAPS; ++t) u += K::g(e, t) * w[t];
-        wu[((long)e * Cin4 + ci) * Mpad + co] = u;
+            for (int t = 0; t < K::TAPS; ++t) u += K::g(e, t) * w[t];
+            wu[(((long)ky * K::NUV + e) * Cin4 + ci) * Mpad + co] = u;
+        }
     }
 }
 
@@ -1062,15 +1080,15 @@ long wino1d_workgroups(const Wino1Args &a, int variant)
     return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * (a.Mpad / wino1d_variant_bm(variant));
 }
 
-void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, hipStream_t s)
+void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, int cross, hipStream_t s)
 {
     const long total = (long)Cin * Mpad;
     const dim3 grid((unsigned)((total + 255) / 256));
     switch (kind) {
-        case 0: hipLaunchKernelGGL(wino1d_repack_kernel<0>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad); break;
-        case 1: hipLaunchKernelGGL(wino1d_repack_kernel<1>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad); break;
-        case 2: hipLaunchKernelGGL(wino1d_repack_kernel<2>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad); break;
-        default: hipLaunchKernelGGL(wino1d_repack_kernel<3>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad); break;
+        case 0: hipLaunchKernelGGL(wino1d_repack_kernel<0>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad, cross); break;
+        case 1: hipLaunchKernelGGL(wino1d_repack_kernel<1>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad, cross); break;
+        case 2: hipLaunchKernelGGL(wino1d_repack_kernel<2>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad, cross); break;
+        default: hipLaunchKernelGGL(wino1d_repack_kernel<3>, grid, dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad, cross); break;
     }
 }
 

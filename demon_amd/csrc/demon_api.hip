@@ -66,9 +66,12 @@ struct Layer {
     float *d_w1 = nullptr;
     mutable bool w1_dirty = true;
     int wino1d_axis() const { return kw == 1 ? 0 : 1; }
+    int wino1d_cross() const { return (kh == 3 && kw == 3) ? 3 : 1; }   // 3 x 3 stride 1: three 1 x 3 filters summed in the same accumulators
     int wino1d_kind_of() const
     {
-        if (kind != CONV || scale || Cin < 16 || (kh != 1 && kw != 1) || (kh == 1 && kw == 1)) return -1;
+        if (kind != CONV || scale || Cin < 16) return -1;
+        if (kh == 3 && kw == 3) return (sh == 1 && sw == 1 && ph == 1 && pw == 1) ? 0 : -1;
+        if ((kh != 1 && kw != 1) || (kh == 1 && kw == 1)) return -1;
         if (kw == 1 && sw != 1) return -1;
         if (kh == 1 && sh != 1) return -1;
         return wino1d_kind(kw == 1 ? kh : kw, kw == 1 ? sh : sw);
@@ -274,7 +277,7 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
         }
     }
     if (L->wino1d_kind_of() >= 0 && !getenv("DEMON_NO_WINO")) {
-        const size_t nu = ((size_t)wino1d_nuv(L->wino1d_kind_of()) * L->Cin4() + 8) * L->Mpad;   // + 8 rows: the two-K-group variants read (and multiply by zeros) up to 4 rows past the end
+        const size_t nu = ((size_t)L->wino1d_cross() * wino1d_nuv(L->wino1d_kind_of()) * L->Cin4() + 8) * L->Mpad;   // + 8 rows: the two-K-group variants read (and multiply by zeros) up to 4 rows past the end
         L->d_w1 = dev_alloc(c, sizeof(float) * nu);
         if (!L->d_w1 || hipMemset(L->d_w1, 0, sizeof(float) * nu) != hipSuccess) return false;
         L->w1_dirty = true;
@@ -586,7 +589,7 @@ void run_small(const Layer *L, const ConvArgs &a, hipStream_t s)
 void refresh_stream_weights(const Layer *L, hipStream_t s)
 {
     if (L->d_w1 && L->w1_dirty) {   // transformed weights of the 1-D minimal-filtering kernel (conv_wino.hip)
-        launch_wino1d_repack(L->d_w1, L->d_wp, L->wino1d_kind_of(), L->Cin, L->Cin4(), L->Mpad, s);
+        launch_wino1d_repack(L->d_w1, L->d_wp, L->wino1d_kind_of(), L->Cin, L->Cin4(), L->Mpad, L->wino1d_cross(), s);
         L->w1_dirty = false;
     }
     if (L->d_wu && L->wu_dirty) {   // transformed weights of the minimal-filtering 3 x 3 kernel (conv_wino.hip)
@@ -728,7 +731,10 @@ bool fill_wino1d_args(const Layer *L, const ConvArgs &a, int variant, Wino1Args 
     w.act = a.act; w.xcd = a.xcd;
     w.pad = L->wino1d_axis() == 0 ? L->ph : L->pw;
     const int cks = 4 * wino1d_variant_kg(variant);
-    w.nsteps_total = (L->Cin + cks - 1) / cks;
+    w.cross = L->wino1d_cross();
+    w.cross_pad = w.cross > 1 ? L->ph : 0;
+    w.csteps = (L->Cin + cks - 1) / cks;
+    w.nsteps_total = w.cross * w.csteps;
     w.ksplit = 1;
     return wino1d_plan_geometry(w, L->wino1d_kind_of(), variant, L->wino1d_axis(), a.N);
 }
@@ -742,7 +748,7 @@ bool run_wino1d(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipS
     if (ksplit > w.nsteps_total) ksplit = w.nsteps_total;
     w.ksplit = ksplit;
     launch_wino1d(w, L->wino1d_kind_of(), variant, L->wino1d_axis(), s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino1d<t%d,v%d>%s", L->wino1d_axis() == 0 ? L->kh : L->kw, variant, split_suffix(ksplit, false));
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino1d<t%d%s,v%d>%s", L->wino1d_axis() == 0 ? L->kh : L->kw, L->wino1d_cross() > 1 ? "x3" : "", variant, split_suffix(ksplit, false));
     g_last_kernel = g_kernel_tag;
     if (ksplit > 1) {
         ConvArgs r = a;
@@ -946,7 +952,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
         for (int v = 0; v < WINO1D_VARIANTS; ++v) {
             Wino1Args w;
             if (!fill_wino1d_args(L, a, v, w)) continue;
-            const int nsteps = w.nsteps_total * wino1d_variant_kg(v);
+            const int nsteps = w.csteps * wino1d_variant_kg(v);
             const long wgs = wino1d_workgroups(w, v);
             for (int ks : {1, 2, 3, 4, 6, 8}) {
                 if (ks > 1 && (ks > nsteps / 8 || wgs * ks > 4096 || (long)ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;

@@ -349,6 +349,8 @@ struct Wino1Args {
     long out_n_stride, out_plane;
     int act, ksplit, nsteps_total;       // K-steps of 4 input channels
     int pad;                             // zeros in front of the first input sample along the filter axis
+    int cross, csteps, cross_pad;        // taps across the filter axis (1, or 3: a 3 x 3 kernel as three 1 x 3 filters), channel steps per
+                                         // cross tap (nsteps_total = cross * csteps), zeros in front of the first row across the axis
     int G, TY, TX, tiles_y, tiles_x;     // workgroup tile = G images x TY x TX tiles (a tile = 2 outputs along the filter axis)
     int xcd;
     unsigned m_tytx, m_tx, m_tilesx, m_tilesy;
@@ -361,7 +363,7 @@ int wino1d_variant_bm(int v);
 bool wino1d_variant_ok(int kind, int v);
 bool wino1d_plan_geometry(Wino1Args &a, int kind, int variant, int axis, int n);
 long wino1d_workgroups(const Wino1Args &a, int variant);
-void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, hipStream_t s);
+void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, int cross, hipStream_t s);
 void launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream);
 
 // ---- tiny heads (conv_small.hip): VALU direct conv for Cout <= 4, fused motion tail -------------------------------------

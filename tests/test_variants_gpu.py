@@ -200,7 +200,8 @@ def test_minimal_filtering_conv3x3(gpu_ctx, shape):
 # (cin, cout, kh, kw, sh, sw, H, W)
 WINO1D_LAYERS = [(64, 64, 3, 1, 1, 1, 24, 32), (128, 128, 1, 3, 1, 1, 12, 16), (64, 128, 5, 1, 2, 1, 48, 64), (128, 128, 1, 5, 1, 2, 24, 64),
                  (32, 64, 7, 1, 2, 1, 24, 32), (32, 32, 1, 7, 1, 2, 12, 64), (32, 32, 1, 9, 1, 2, 12, 64), (16, 32, 9, 1, 2, 1, 48, 64),
-                 (18, 40, 3, 1, 1, 1, 7, 9), (30, 24, 1, 5, 1, 2, 5, 23), (20, 36, 7, 1, 2, 1, 17, 33), (256, 256, 3, 1, 1, 1, 12, 16), (34, 32, 1, 9, 1, 2, 9, 31)]
+                 (18, 40, 3, 1, 1, 1, 7, 9), (30, 24, 1, 5, 1, 2, 5, 23), (20, 36, 7, 1, 2, 1, 17, 33), (256, 256, 3, 1, 1, 1, 12, 16), (34, 32, 1, 9, 1, 2, 9, 31),
+                 (130, 24, 3, 3, 1, 1, 48, 64), (64, 16, 3, 3, 1, 1, 40, 72), (64, 64, 3, 3, 1, 1, 24, 32), (18, 40, 3, 3, 1, 1, 7, 9)]   # 3 x 3: three 1 x 3 filters
 
 
 @pytest.mark.parametrize("layer", WINO1D_LAYERS)

@@ -21,7 +21,9 @@ CONV1D = [("conv2_1y 64->64 3x1 48x64", 64, 48, 64, 64, 3, 1, 1, 1), ("conv2_1x 
           ("conv5_1y 512->512 3x1 6x8", 512, 6, 8, 512, 3, 1, 1, 1),
           ("conv3y 64->128 5x1 s2 48x64", 64, 48, 64, 128, 5, 1, 2, 1), ("conv3x 128->128 1x5 s2 24x64", 128, 24, 64, 128, 1, 5, 1, 2),
           ("conv2y 32->32 7x1 s2 96x128", 32, 96, 128, 32, 7, 1, 2, 1), ("conv2x 32->32 1x7 s2 48x128", 32, 48, 128, 32, 1, 7, 1, 2),
-          ("conv1x 32->32 1x9 s2 96x256", 32, 96, 256, 32, 1, 9, 1, 2)]
+          ("conv1x 32->32 1x9 s2 96x256", 32, 96, 256, 32, 1, 9, 1, 2),
+          ("predict2 conv1 130->24 3x3", 130, 48, 64, 24, 3, 3, 1, 1), ("predict_depth0 conv1 64->16 3x3", 64, 192, 256, 16, 3, 3, 1, 1),
+          ("rf conv1_1 64->64 3x3", 64, 96, 128, 64, 3, 3, 1, 1), ("rf conv2_1 128->128 3x3", 128, 48, 64, 128, 3, 3, 1, 1)]
 
 
 def main():
@@ -29,6 +31,7 @@ def main():
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--skip-deconv", action="store_true")
     ap.add_argument("--skip-conv3", action="store_true")
+    ap.add_argument("--only1d", default="", help="substring filter on the 1-D layer labels")
     args = ap.parse_args()
     ctx = DemonContext(0, 1)
     for lab, cin, h, w, cout in ([] if args.skip_deconv else LAYERS):
@@ -89,6 +92,8 @@ def main():
         print(line, flush=True)
     # separable layers: best direct plan vs 1-D minimal filtering
     for lab, cin, h, w, cout, kh, kw, sh, sw in CONV1D:
+        if args.only1d and args.only1d not in lab:
+            continue
         line = "%-30s" % lab
         best = None
         cands = [(-1, 0)] + [(100 + t, 0) for t in range(6)] + [(300 + v, ks) for v in (0, 1, 2, 4, 6, 8, 9) for ks in (1, 2)]
