@@ -1,4 +1,4 @@
-// conv_wino.hip -- minimal-filtering (Winograd / Toom-Cook) forms of the two MFMA-bound layer classes, on fp32 MFMA.
+// conv_wino.hip -- minimal-filtering (Winograd / Toom-Cook) forms of the transposed convs and of the k x 1 / 1 x k / 3 x 3 convs, on fp32 MFMA.
 //
 // The transposed convs (blocks_original.py:64-75, :97-110; `refine*/upconv`, 27 % of a batch-32 pass at 105-113 TFLOP/s, i.e. at
 // what the matrix pipe gives under load) are four 2 x 2 sub-pixel convolutions.  F(2,2) computes two outputs of a 2-tap filter with
@@ -344,265 +344,12 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
 }
 
 // =====================================================================================================================================
-// 3 x 3 stride-1 convolutions (helpers.py:70-102 with k = 3: `conv1_1`, `conv2_1` of the refinement net, the `predict_*/conv1` heads):
-// F(2x2, 3x3) -- a 2 x 2 output tile from its 4 x 4 input window with 16 multiplications instead of 36 (2.25 x fewer MFMAs):
-//       Y = At [ (G g Gt) . (Bt d B) ] A,   Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],
-//                                           At = [1 1 1 0; 0 1 -1 -1]
-// U = G g Gt is precomputed per layer (wino3_repack_kernel, [uv][ci][Mpad], channels padded to 4 with zeros).  The input transform
-// costs 32 vector-ALU operations per tile and channel -- as much SIMD time as 4 of the 16 MFMAs it feeds (fp32 MFMA and VALU share
-// the SIMD) -- so it is NOT done per wave: the threads of a workgroup transform each (tile, channel) ONCE while staging it, write
-// the 16 transformed values to LDS as the B operand [uv][k][tile], and the WM waves that own different 16-channel blocks of the same
-// tiles all read them (BM = 64: 0.5 VALU operations per MFMA instead of 2).
-// Wave = 16 channels x 32 tiles x 16 (u,v) = 32 accumulators of 4 registers; workgroup = WM channel blocks x WN tile groups, 4 waves.
-// Staging unit = (tile, channel, half): the rows u = 2 half, 2 half + 1 of Bt d B from 3 input rows x 4 columns (12 buffer loads with
-// out-of-range offsets for the zero padding, 16 VALU operations, 8 LDS stores); WN units per thread, `half` is uniform per wave.
-template <int WM, int WN, bool MASK>
-__global__ __launch_bounds__(64 * WM * WN, 2) void wino_conv3_kernel(Wino3Args a)
-{
-    constexpr int NT = 64 * WM * WN, CKS = 4, TN = 2;
-    constexpr int BM = 16 * WM, NTILE = 32 * WN, UNITS = 4 / WM;   // half-tile staging units per thread: 2 * 4 * NTILE / NT
-    constexpr int TP = NTILE + 16;                 // row pitch of T: the k = 0 / k = 1 halves of a 32-lane LDS access use different banks
-    constexpr int ASZ = 16 * CKS * BM, TSZ = 16 * CKS * TP;
-    constexpr int APER = 16 * BM / NT;             // 16-byte chunks of the weight tile per thread
-    static_assert((WM == 4 || WM == 2) && (16 * BM) % NT == 0 && APER >= 1, "bad shape");
-    constexpr int OOB = 0x7ffffff0, NREC = 0x40000000;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // As[2][ASZ], Ts[2][TSZ]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l15 = lane & 15, lk = lane >> 4;
-    const int zs = blockIdx.z;
-    unsigned bx, by;
-    xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
-    const int m0 = by * BM;
-    const int tyg = wdiv((int)bx, a.m_tilesx);
-    const int tx = (int)bx - tyg * a.tiles_x;
-    const int tgrp = wdiv(tyg, a.m_tilesy);
-    const int ty = tyg - tgrp * a.tiles_y;
-    const int n0 = tgrp * a.G;
-    const int y_org = ty * a.TY * 2 - 1, x_org = tx * a.TX * 2 - 1;   // input coordinates of the window of tile (0,0)
-    const float *__restrict__ in0 = a.in + (long)n0 * a.in_n_stride;
-    const int ntile = a.G * a.TY * a.TX;
-
-    // ---- staging units: unit i of this thread = (tile q, channel k, half)
-    int goff[UNITS][12], tw[2][UNITS];
-    unsigned lastmask = 0;   // bit i: unit i's channel exists in the last K-step
-    int uhalf[UNITS];
-    const int last_c0 = (a.nsteps_total - 1) * CKS;
-#pragma unroll
-    for (int i = 0; i < UNITS; ++i) {
-        // unit w of [2 halves][4 channels][NTILE tiles]; WM = 4: one unit per thread, the upper half of the workgroup takes half 1;
-        // WM = 2: two units per thread, unit i = half i -- either way `half` is uniform per wave
-        const int w = tid + i * NT;
-        const int half = w / (4 * NTILE), wr = w - half * (4 * NTILE);
-        const int k = wr / NTILE, q = wr - k * NTILE;
-        uhalf[i] = half;
-        const bool qv = q < ntile;
-        const int qc = qv ? q : 0;
-        const int g = wdiv(qc, a.m_tytx), rem = qc - g * (a.TY * a.TX);
-        const int r = wdiv(rem, a.m_tx), c = rem - r * a.TX;
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int gy = y_org + 2 * r + half + j, gx = x_org + 2 * c + ii;
-                const bool ok = qv & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
-                goff[i][j * 4 + ii] = ok ? 4 * (g * (int)a.in_n_stride + k * a.H * a.W + gy * a.W + gx) : OOB;
-            }
-        tw[0][i] = 2 * ASZ + ((2 * half) * 4 * CKS + k) * TP + q;
-        tw[1][i] = tw[0][i] + TSZ;
-        asm volatile("" : "+v"(tw[1][i]));
-        lastmask |= ((last_c0 + k < a.Cin) ? 1u : 0u) << i;
-    }
-    // ---- weight loader: chunk f = tid + i*NT of the [uv][channel block][k][16] tile <-> U[uv][c0 + k][m0 + 16 blk + 4 c4 ..]
-    int aoff[APER];
-#pragma unroll
-    for (int i = 0; i < APER; ++i) {
-        const int f = tid + i * NT;
-        const int c4 = f & 3, k = (f >> 2) & 3, blk = (f >> 4) % WM, uv = f / (16 * WM);
-        aoff[i] = 4 * (int)(((long)uv * a.Cin4 + k) * a.Mpad + m0 + blk * 16 + c4 * 4);
-    }
-    // ---- fragment addressing
-    int ra[2], rt[2];
-    ra[0] = wm * 64 + lane;
-    ra[1] = ra[0] + ASZ;
-    rt[0] = 2 * ASZ + lk * TP + wn * 32 + l15;
-    rt[1] = rt[0] + TSZ;
-    asm volatile("" : "+v"(ra[1]));
-    asm volatile("" : "+v"(rt[1]));
-
-    floatx4 acc[TN][16];
-#pragma unroll
-    for (int tb = 0; tb < TN; ++tb)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[tb][q] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    float preg[UNITS][12];
-    floatx4 areg[APER];
-    auto load_tiles = [&](int step) {
-        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * a.H * a.W), 0, NREC, 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)step * CKS * a.Mpad), 0, NREC, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i)
-#pragma unroll
-            for (int e = 0; e < 12; ++e) preg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][e], 0, 0));
-#pragma unroll
-        for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
-    };
-    // rows u = 2 half, 2 half + 1 of Bt d B for one unit -> T[uv][k][tile]
-    // `step`: the K-step the registers hold; in the last one the channels past Cin (they were read from whatever follows the input
-    // in memory) are replaced by zeros
-    auto transform_store = [&](int buf, int step) {
-        const bool last = MASK && step == a.nsteps_total - 1;   // (uniform)
-#pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            const float *l = preg[i];   // l[j*4 + c]: loaded row j (= input row half + j), column c
-            float r0[4], r1[4];
-            if (uhalf[i] == 0) {        // u = 0: d0 - d2;  u = 1: d1 + d2
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { r0[c] = l[c] - l[8 + c]; r1[c] = l[4 + c] + l[8 + c]; }
-            } else {                    // u = 2: d2 - d1;  u = 3: d1 - d3   (loaded rows are d1, d2, d3)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { r0[c] = l[4 + c] - l[c]; r1[c] = l[c] - l[8 + c]; }
-            }
-            float t[8] = {r0[0] - r0[2], r0[1] + r0[2], r0[2] - r0[1], r0[1] - r0[3], r1[0] - r1[2], r1[1] + r1[2], r1[2] - r1[1], r1[1] - r1[3]};
-            if constexpr (MASK) {
-                if (last) {
-                    const bool dead = !((lastmask >> i) & 1u);
-#pragma unroll
-                    for (int v = 0; v < 8; ++v) t[v] = dead ? 0.0f : t[v];
-                }
-            }
-            float *T = smem + tw[buf][i];
-#pragma unroll
-            for (int v = 0; v < 8; ++v) T[(v * CKS) * TP] = t[v];
-        }
-#pragma unroll
-        for (int i = 0; i < APER; ++i) *reinterpret_cast<floatx4 *>(smem + buf * ASZ + (tid + i * NT) * 4) = areg[i];
-    };
-    auto compute = [&](int buf) {
-        const float *A = smem + ra[buf];
-        const float *T = smem + rt[buf];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {   // (u,v) outer: one weight fragment feeds both tile blocks and is dead afterwards
-            const float af = A[q * (WM * 64)];
-#pragma unroll
-            for (int tb = 0; tb < TN; ++tb)
-                acc[tb][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, T[q * CKS * TP + tb * 16], acc[tb][q], 0, 0, 0);
-        }
-    };
-
-    const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
-    const int s_begin = zs * per_slice;
-    const int nsteps = min(a.nsteps_total, s_begin + per_slice) - s_begin;
-    // loads run one K-step ahead: step s on buffer s&1: loads of step s+1 | MFMAs of step s | transform + LDS stores of step s+1 | barrier
-    if (nsteps > 0) {
-        load_tiles(s_begin);
-        transform_store(0, s_begin);
-    }
-    __syncthreads();
-    {
-        int s = 0;
-        for (; s + 2 < nsteps; s += 2) {
-            load_tiles(s_begin + s + 1);
-            compute(0);
-            transform_store(1, s_begin + s + 1);
-            __syncthreads();
-            load_tiles(s_begin + s + 2);
-            compute(1);
-            transform_store(0, s_begin + s + 2);
-            __syncthreads();
-        }
-        if (s + 1 < nsteps) {
-            load_tiles(s_begin + s + 1);
-            compute(0);
-            transform_store(1, s_begin + s + 1);
-            __syncthreads();
-            compute(1);
-        } else if (nsteps > 0) {
-            compute(0);
-        }
-    }
-
-    // ---- epilogue: Y = At M A per tile; lane = tile, registers = 4 consecutive channels
-    const long P = (long)a.N * a.H * a.W;
-#pragma unroll
-    for (int tb = 0; tb < TN; ++tb) {
-        const int q = wn * 32 + tb * 16 + l15;
-        if (q >= ntile) continue;
-        const int g = wdiv(q, a.m_tytx), rem = q - g * (a.TY * a.TX);
-        const int r = wdiv(rem, a.m_tx), c = rem - r * a.TX;
-        const int n = n0 + g;
-        const int y0 = (ty * a.TY + r) * 2, x0 = (tx * a.TX + c) * 2;
-        if (n >= a.N || y0 >= a.H || x0 >= a.W) continue;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int co = m0 + wm * 16 + 4 * lk + e;
-            float s0[4], s1[4];   // rows: At M
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                s0[v] = (acc[tb][v][e] + acc[tb][4 + v][e]) + acc[tb][8 + v][e];
-                s1[v] = (acc[tb][4 + v][e] - acc[tb][8 + v][e]) - acc[tb][12 + v][e];
-            }
-            float o[2][2];
-            o[0][0] = (s0[0] + s0[1]) + s0[2]; o[0][1] = (s0[1] - s0[2]) - s0[3];
-            o[1][0] = (s1[0] + s1[1]) + s1[2]; o[1][1] = (s1[1] - s1[2]) - s1[3];
-            if (a.ksplit > 1) {   // partial sums in output space, layout [slice][Mpad][P] (conv_splitk_reduce finishes)
-                float *__restrict__ ws = a.ws + ((long)zs * a.Mpad + co) * P + ((long)n * a.H + y0) * a.W + x0;
-#pragma unroll
-                for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-                    for (int ib = 0; ib < 2; ++ib)
-                        if (y0 + ia < a.H && x0 + ib < a.W) ws[ia * a.W + ib] = o[ia][ib];
-            } else if (co < a.Cout) {
-                const float b = a.bias[co];
-                float *__restrict__ ob = a.out + (long)n * a.out_n_stride + (long)co * a.out_plane + (long)y0 * a.W + x0;
-#pragma unroll
-                for (int ia = 0; ia < 2; ++ia) {
-                    float v0 = o[ia][0] + b, v1 = o[ia][1] + b;
-                    if (a.act) { v0 = fmaxf(v0, 0.1f * v0); v1 = fmaxf(v1, 0.1f * v1); }
-                    if (y0 + ia < a.H) {
-                        if ((a.W & 1) == 0) *reinterpret_cast<float2 *>(ob + (long)ia * a.W) = float2{v0, v1};
-                        else { ob[(long)ia * a.W] = v0; if (x0 + 1 < a.W) ob[(long)ia * a.W + 1] = v1; }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// U[uv][ci][co] = (G g Gt)[u][v] from the packed 3 x 3 weights wp[(a*3 + b)*Cin + ci][co]; rows ci >= Cin of U stay zero
-__global__ __launch_bounds__(256) void wino3_repack_kernel(float *__restrict__ wu, const float *__restrict__ wp, int Cin, int Cin4, int Mpad)
-{
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)Cin * Mpad) return;
-    const int ci = (int)(idx / Mpad), co = (int)(idx - (long)ci * Mpad);
-    float g[3][3], t[4][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) g[a][b] = wp[((long)(a * 3 + b) * Cin + ci) * Mpad + co];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        t[0][b] = g[0][b];
-        t[1][b] = 0.5f * ((g[0][b] + g[2][b]) + g[1][b]);
-        t[2][b] = 0.5f * ((g[0][b] + g[2][b]) - g[1][b]);
-        t[3][b] = g[2][b];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const float U[4] = {t[u][0], 0.5f * ((t[u][0] + t[u][2]) + t[u][1]), 0.5f * ((t[u][0] + t[u][2]) - t[u][1]), t[u][2]};
-#pragma unroll
-        for (int v = 0; v < 4; ++v) wu[((long)(u * 4 + v) * Cin4 + ci) * Mpad + co] = U[v];
-    }
-}
-
-// =====================================================================================================================================
 // k x 1 / 1 x k convolutions (the separable pairs of helpers.py:105-153): two consecutive outputs along the filter axis from one
 // window of inputs with fewer multiplications -- F(2,3) for the 3-tap stride-1 layers (4 instead of 6), and for the stride-2 layers
 // the polyphase split (even / odd input samples see the even / odd taps as stride-1 filters) with F(2,re) + F(2,ro): 7 instead of 10
 // (5 taps), 9 instead of 14 (7 taps), 11 instead of 18 (9 taps).  Transforms: wino1d_tables.h (generated, checked in exact
-// rationals).  Structure as wino_conv3_kernel: the threads of a workgroup transform every (tile, channel) window ONCE at staging time
+// rationals).  The input transform costs vector-ALU time, which fp32 MFMAs share with the matrix work, so it is NOT done per wave:
+// the threads of a workgroup transform every (tile, channel) window ONCE at staging time
 // and write the NUV values to LDS ([e][k][tile]); WM waves owning different 16-channel blocks read them as the MFMA B operand.
 //   AXIS 0: k x 1 filter, tile = outputs (2r, c), (2r+1, c);  AXIS 1: 1 x k filter, tile = outputs (r, 2c), (r, 2c+1)
 // KG: MFMA K groups (of 4 input channels) per K-step, i.e. per barrier.  MASK: Cin is not a multiple of 4 KG -- the channels of the
@@ -933,84 +680,6 @@ void launch_wino_deconv(const WinoArgs &a, int variant, hipStream_t stream)
         case 1: launch_wino_ept<1, 4>(a, grid, lds, stream); break;
         default: launch_wino_ept<4, 2>(a, grid, lds, stream); break;
     }
-}
-
-
-// ---- 3 x 3 host side
-// variants: (channel blocks of 16) x (tile groups of 32) per workgroup
-int wino3_variant_wm(int v) { return (v & 1) ? 2 : 4; }
-int wino3_variant_wn(int v) { return v == 0 ? 2 : (v == 1 ? 4 : (v == 2 ? 1 : 2)); }   // 0: 4x2, 1: 2x4 (8 waves); 2: 4x1, 3: 2x2 (4 waves)
-
-static size_t wino3_lds_bytes(int wm, int wn)
-{
-    return sizeof(float) * 2ul * (16 * WINO_CKS * 16 * wm + 16 * WINO_CKS * (32 * wn + 16));
-}
-
-// Workgroup tile of 32 * WN tiles: G images x TY x TX tiles, TX <= 16
-bool wino3_plan_geometry(Wino3Args &a, int variant, int n)
-{
-    const int wm = wino3_variant_wm(variant), ntile = 32 * wino3_variant_wn(variant);
-    if (a.Mpad % (16 * wm)) return false;
-    const int ity = (a.H + 1) / 2, itx = (a.W + 1) / 2;
-    double best = 1e30;
-    bool ok = false;
-    for (int TX : {16, 8, 4, itx}) {
-        if (TX > 16 || TX > itx || TX < 1) continue;
-        int TY = ntile / TX;
-        if (TY < 1) continue;
-        if (TY > ity) TY = ity;
-        int G = 1;
-        if (TY == ity && TX == itx) { G = ntile / (TY * TX); if (G < 1) G = 1; if (G > n) G = n; }
-        const int tiles_y = (ity + TY - 1) / TY, tiles_x = (itx + TX - 1) / TX, groups = (n + G - 1) / G;
-        const double waste = (double)groups * tiles_y * tiles_x * ntile / ((double)n * ity * itx);
-        const double cost = waste * (1.0 + 0.02 * (16.0 / TX));
-        if (cost < best) {
-            best = cost;
-            ok = true;
-            a.G = G; a.TY = TY; a.TX = TX; a.tiles_y = tiles_y; a.tiles_x = tiles_x;
-        }
-    }
-    if (!ok) return false;
-    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
-    a.m_tytx = magic(a.TY * a.TX); a.m_tx = magic(a.TX); a.m_tilesx = magic(a.tiles_x); a.m_tilesy = magic(a.tiles_y);
-    return true;
-}
-
-long wino3_workgroups(const Wino3Args &a, int variant)
-{
-    return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * (a.Mpad / (16 * wino3_variant_wm(variant)));
-}
-
-void launch_wino3_repack(float *wu, const float *wp, int Cin, int Cin4, int Mpad, hipStream_t s)
-{
-    const long total = (long)Cin * Mpad;
-    hipLaunchKernelGGL(wino3_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad);
-}
-
-void launch_wino_conv3(const Wino3Args &a, int variant, hipStream_t stream)
-{
-    const int wm = wino3_variant_wm(variant), wn = wino3_variant_wn(variant);
-    const int groups = (a.N + a.G - 1) / a.G;
-    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / (16 * wm)), (unsigned)a.ksplit);
-    const size_t lds = wino3_lds_bytes(wm, wn);
-    static bool configured = false;
-    if (!configured) {   // 8-wave shapes need more than the default 64 KB of dynamic LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(4, 2));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<2, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(2, 4));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<4, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(4, 2));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_conv3_kernel<2, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wino3_lds_bytes(2, 4));
-        configured = true;
-    }
-#define W3_LAUNCH(WMM, WNN, THREADS)                                                                                         \
-    if (a.Cin & 3) hipLaunchKernelGGL((wino_conv3_kernel<WMM, WNN, true>), grid, dim3(THREADS), lds, stream, a);             \
-    else hipLaunchKernelGGL((wino_conv3_kernel<WMM, WNN, false>), grid, dim3(THREADS), lds, stream, a)
-    switch (variant) {
-        case 0: W3_LAUNCH(4, 2, 512); break;
-        case 1: W3_LAUNCH(2, 4, 512); break;
-        case 2: W3_LAUNCH(4, 1, 256); break;
-        default: W3_LAUNCH(2, 2, 256); break;
-    }
-#undef W3_LAUNCH
 }
 
 

@@ -58,9 +58,6 @@ struct Layer {
     float *d_wf = nullptr;
     const float *zero = nullptr;
     mutable bool wf_dirty = true;
-    // conv_wino.hip, 3 x 3 stride-1 convs: U = G g Gt [16][Cin4][Mpad], refreshed from d_wp like d_wf
-    float *d_wu = nullptr;
-    mutable bool wu_dirty = true;
     int Cin4() const { return (Cin + 3) / 4 * 4; }
     // 1-D minimal filtering (conv_wino.hip): k x 1 / 1 x k layers with 3 taps stride 1 or 5 / 7 / 9 taps stride 2; U[e][Cin4][Mpad] in d_w1
     float *d_w1 = nullptr;
@@ -76,7 +73,6 @@ struct Layer {
         if (kh == 1 && sh != 1) return -1;
         return wino1d_kind(kw == 1 ? kh : kw, kw == 1 ? sh : sw);
     }
-    bool wino3_shape() const { return kind == CONV && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && Cin >= 16 && !scale; }
     bool have_kernel = false, have_bias = false;
     std::vector<int64_t> kernel_dims;  // TF layout
     int force_tile = -1, force_split = 0;  // tuning override (demon_bench_layer)
@@ -282,12 +278,6 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
         if (!L->d_w1 || hipMemset(L->d_w1, 0, sizeof(float) * nu) != hipSuccess) return false;
         L->w1_dirty = true;
     }
-    if (L->wino3_shape() && !getenv("DEMON_NO_WINO")) {
-        const size_t nu = (size_t)16 * L->Cin4() * L->Mpad;
-        L->d_wu = dev_alloc(c, sizeof(float) * nu);
-        if (!L->d_wu || hipMemset(L->d_wu, 0, sizeof(float) * nu) != hipSuccess) return false;
-        L->wu_dirty = true;
-    }
     if (!alloc_weights) return true;  // network layers: alloc_weight_slab() places d_wp / d_bias once all layers exist
     L->d_wp = dev_alloc(c, sizeof(float) * (size_t)L->ncls * L->Krows * L->Mpad);
     L->d_bias = dev_alloc(c, sizeof(float) * L->Mpad);
@@ -349,7 +339,6 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
     HIP_TRY(c, hipMemcpy(L->d_wp, wp.data(), wp.size() * sizeof(float), hipMemcpyHostToDevice));
     L->have_kernel = true;
     L->wf_dirty = true;
-    L->wu_dirty = true;
     L->w1_dirty = true;
     return DEMON_OK;
 }
@@ -592,10 +581,6 @@ void refresh_stream_weights(const Layer *L, hipStream_t s)
         launch_wino1d_repack(L->d_w1, L->d_wp, L->wino1d_kind_of(), L->Cin, L->Cin4(), L->Mpad, L->wino1d_cross(), s);
         L->w1_dirty = false;
     }
-    if (L->d_wu && L->wu_dirty) {   // transformed weights of the minimal-filtering 3 x 3 kernel (conv_wino.hip)
-        launch_wino3_repack(L->d_wu, L->d_wp, L->Cin, L->Cin4(), L->Mpad, s);
-        L->wu_dirty = false;
-    }
     if (!L->d_wf || !L->wf_dirty) return;
     launch_stream_repack(L->d_wf, L->d_wp, L->ncls, L->K, L->Mpad, (long)L->Krows * L->Mpad, s);
     L->wf_dirty = false;
@@ -693,33 +678,6 @@ bool run_wino(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStr
     return true;
 }
 
-// F(2x2, 3x3) for the 3 x 3 stride-1 convs (conv_wino.hip), plan kind 9: variant = workgroup shape, ksplit slices over the input channels
-bool wino3_applies(const Layer *L) { return L->d_wu != nullptr && L->wino3_shape(); }
-
-bool run_wino3(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
-{
-    refresh_stream_weights(L, s);
-    Wino3Args w;
-    w.in = a.in; w.out = a.out; w.wu = L->d_wu; w.bias = a.bias; w.ws = a.ws;
-    w.N = a.N; w.Cin = L->Cin; w.Cin4 = L->Cin4(); w.H = a.H; w.W = a.W; w.in_n_stride = a.in_n_stride;
-    w.Cout = L->Cout; w.Mpad = L->Mpad; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
-    w.act = a.act; w.xcd = a.xcd;
-    w.nsteps_total = L->Cin4() / 4;
-    if (variant < 0 || variant >= WINO3_VARIANTS || !wino3_plan_geometry(w, variant, a.N)) return false;
-    if (ksplit < 1) ksplit = 1;
-    if (ksplit > w.nsteps_total) ksplit = w.nsteps_total;
-    w.ksplit = ksplit;
-    launch_wino_conv3(w, variant, s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino_conv3<%dx%d>%s", 16 * wino3_variant_wm(variant), 32 * wino3_variant_wn(variant), split_suffix(ksplit, false));
-    g_last_kernel = g_kernel_tag;
-    if (ksplit > 1) {
-        ConvArgs r = a;
-        r.ksplit = ksplit;
-        launch_splitk_reduce(r, L->ncls, s);
-    }
-    return true;
-}
-
 // 1-D minimal filtering for the k x 1 / 1 x k convs (conv_wino.hip), plan kind 10: variant = workgroup shape
 bool wino1d_applies(const Layer *L) { return L->d_w1 != nullptr && L->wino1d_kind_of() >= 0; }
 
@@ -797,8 +755,6 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 }
             } else if (kind == 10) {
                 if (wino1d_applies(L) && run_wino1d(L, a, tile, clamp_split(ks % 1000), s)) return;
-            } else if (kind == 9) {
-                if (wino3_applies(L) && run_wino3(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 8) {
                 if (wino_applies(L) && tile >= 0 && tile < WINO_VARIANTS && run_wino(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 1) {
@@ -832,7 +788,6 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 return;
             }
             if (t.kind == 8 && wino_applies(L) && run_wino(L, a, t.tile, clamp_split(t.ksplit), s)) return;
-            if (t.kind == 9 && wino3_applies(L) && run_wino3(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 10 && wino1d_applies(L) && run_wino1d(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
@@ -848,10 +803,9 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             }
         }
     }
-    if (L->force_tile >= 400) {  // demon_bench_layer: minimal-filtering variant force_tile - 400 (transposed conv / 3 x 3 conv)
+    if (L->force_tile >= 400) {  // demon_bench_layer: minimal-filtering variant force_tile - 400 (transposed conv / k x 1, 1 x k, 3 x 3 conv)
         const int v = L->force_tile - 400;
         if (wino_applies(L) && v < WINO_VARIANTS && run_wino(L, a, v, clamp_split(L->force_split), s)) return;
-        if (wino3_applies(L) && v < WINO3_VARIANTS && run_wino3(L, a, v, clamp_split(L->force_split), s)) return;
         if (wino1d_applies(L) && v < WINO1D_VARIANTS && run_wino1d(L, a, v, clamp_split(L->force_split), s)) return;
     }
     if (L->force_tile >= 300 && L->force_tile < 400) {  // demon_bench_layer: fragment-tiled kernel variant force_tile - 300
@@ -958,20 +912,6 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
                 if (ks > 1 && (ks > nsteps / 8 || wgs * ks > 4096 || (long)ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
                 if (wgs * ks < 64) continue;
                 cands.push_back({10, v, ks});
-            }
-        }
-    }
-    if (wino3_applies(L)) {
-        const int nsteps = L->Cin4() / 4;
-        for (int v = 0; v < WINO3_VARIANTS; ++v) {
-            Wino3Args w;
-            w.N = n; w.H = a.H; w.W = a.W; w.Mpad = L->Mpad;
-            if (!wino3_plan_geometry(w, v, n)) continue;
-            const long wgs = wino3_workgroups(w, v);
-            for (int ks : {1, 2, 3, 4, 6, 8}) {
-                if (ks > 1 && (ks > nsteps / 8 || wgs * ks > 4096 || (long)ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
-                if (wgs * ks < 64) continue;
-                cands.push_back({9, v, ks});
             }
         }
     }
@@ -2040,7 +1980,7 @@ void slab_arrived(demon_ctx *c)
 {
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
-    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->wu_dirty = true; L->w1_dirty = true; }
+    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->w1_dirty = true; }
 }
 }  // namespace
 extern "C" {
@@ -2216,16 +2156,15 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
 {
     if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
     // kinds: 0 im2col, 1 patch-staged, 3 small-Cout, 4 streaming, 5 fragment-tiled, 6 / 7 = kind 5 / 4 chained with the 1 x k partner
-    // 8 = minimal-filtering transposed conv (conv_wino.hip)
-    if (kind < 0 || kind > 10 || kind == 2 || tile < 0 ||
-        tile >= (kind == 10 ? (int)WINO1D_VARIANTS : kind == 9 ? (int)WINO3_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
+    // 8 = minimal-filtering transposed conv, 10 = 1-D minimal filtering (conv_wino.hip); 9 = the removed F(2x2,3x3) kernel (docs/experiments)
+    if (kind < 0 || kind > 10 || kind == 2 || kind == 9 || tile < 0 ||
+        tile >= (kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
             if (kind == 0 && L->Mpad % conv_tile_bm(tile)) return fail(c, DEMON_ERR_INVALID, "tile does not divide Cout");
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             if (kind == 8 && !wino_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the minimal-filtering kernel applies to transposed convs only");
-            if (kind == 9 && !wino3_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the F(2x2,3x3) kernel applies to 3 x 3 stride-1 convs only");
             if (kind == 10 && !wino1d_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "no 1-D minimal-filtering form for this layer");
             if (kind == 4 && (!L->stream_ok() || L->Mpad % stream_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the streaming kernel does not apply to this layer");
             if (kind == 5 && (!L->stream_ok() || L->Mpad % frag_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the fragment-tiled kernel does not apply to this layer");

@@ -312,30 +312,6 @@ bool wino_plan_geometry(WinoArgs &a, int variant, int n);
 long wino_workgroups(const WinoArgs &a);
 void launch_wino_deconv(const WinoArgs &a, int variant, hipStream_t stream);
 
-// ---- F(2x2, 3x3) for 3 x 3 stride-1 convs (conv_wino.hip) -----------------------------------------------------------------------------
-struct Wino3Args {
-    const float *in;
-    float *out;
-    const float *wu;     // transformed weights U[uv][Cin4][Mpad] (wino3_repack_kernel)
-    const float *bias;
-    float *ws;           // split-K workspace [slice][Mpad][P], partial sums in OUTPUT space
-    int N, Cin, Cin4, H, W;   // input == output geometry (stride 1, one zero in front); Cin4 = Cin rounded up to 4
-    long in_n_stride;
-    int Cout, Mpad;
-    long out_n_stride, out_plane;
-    int act, ksplit, nsteps_total;       // K-steps of 4 input channels
-    int G, TY, TX, tiles_y, tiles_x;     // workgroup tile = G images x TY x TX tiles of 2 x 2 outputs
-    int xcd;
-    unsigned m_tytx, m_tx, m_tilesx, m_tilesy;
-};
-constexpr int WINO3_VARIANTS = 4;   // (16-channel blocks) x (32-tile groups) per workgroup: 4x2, 2x4 (8 waves), 4x1, 2x2 (4 waves)
-int wino3_variant_wm(int v);
-int wino3_variant_wn(int v);
-bool wino3_plan_geometry(Wino3Args &a, int variant, int n);
-long wino3_workgroups(const Wino3Args &a, int variant);
-void launch_wino3_repack(float *wu, const float *wp, int Cin, int Cin4, int Mpad, hipStream_t s);
-void launch_wino_conv3(const Wino3Args &a, int variant, hipStream_t stream);
-
 // ---- 1-D minimal filtering for the k x 1 / 1 x k convs (conv_wino.hip, wino1d_tables.h) -------------------------------------------------
 struct Wino1Args {
     const float *in;

@@ -56,9 +56,6 @@ def kernel_tag(name):
     m = re.search(r"wino_deconv_kernel<(\d+)", name)
     if m:
         return "wino_deconv<16x%d>" % (16 * int(m.group(1)))
-    m = re.search(r"wino_conv3_kernel<(\d+), (\d+)", name)
-    if m:
-        return "wino_conv3<%dx%d>" % (16 * int(m.group(1)), 32 * int(m.group(2)))
     m = re.search(r"wino1d_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
     if m:
         kind, axis, wm, wn, tn = map(int, m.groups())
@@ -83,8 +80,6 @@ def rocprof_kernel_name(tag):
         return "demon::conv_patch_kernel<%s, ...> (%sx%s tile, %s taps)" % (dims[0], dims[0], dims[1], rest.rstrip(">").split(",t")[-1])
     if fam == "wino_deconv" and len(dims) == 2:
         return "demon::wino_deconv_kernel<%d, ...> (16 channels x %s tiles per workgroup)" % (int(dims[1]) // 16, dims[1])
-    if fam == "wino_conv3" and len(dims) == 2:
-        return "demon::wino_conv3_kernel<%d, %d>" % (int(dims[0]) // 16, int(dims[1]) // 32)
     if fam == "wino1d":
         return "demon::wino1d_kernel<...> (%s)" % rest.rstrip(">")
     if fam == "deconv4":

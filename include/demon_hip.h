@@ -102,8 +102,8 @@ int demon_autotune(demon_ctx *ctx, int n);
 /* read back / install launch plans, e.g. to ship the result of one autotune run as a file.  Entry = (kind, tile, ksplit):
  *   kind 0 im2col kernel (conv_mfma.hip), 1 patch-staged kernel (conv_patch.hip; ksplit + 1000 * (pixel-tile shape + 1)),
  *   8 minimal-filtering transposed conv (conv_wino.hip; tile = variant: 32 / 64 / 48 tiles per workgroup),
- *   9 F(2x2,3x3) for 3 x 3 stride-1 convs (conv_wino.hip; tile = workgroup shape 0..3),
- *   10 1-D minimal filtering for k x 1 / 1 x k convs (3 taps stride 1; 5 / 7 / 9 taps stride 2; tile = workgroup shape 0..3),
+ *   10 1-D minimal filtering for k x 1 / 1 x k convs (3 taps stride 1; 5 / 7 / 9 taps stride 2) and 3 x 3 stride-1 convs as three
+ *      1 x 3 filters (conv_wino.hip; tile = workgroup shape 0..7); 9 is not used (a removed experiment),
  *        3 small-Cout VALU kernel, 4 register-streaming kernel (conv_stream.hip), 5 fragment-tiled kernel (conv_frag.hip),
  *        6 / 7 on the k x 1 layer of a stride-1 pair: the pair runs as ONE chained launch of conv_frag / conv_stream variant `tile`;
  *   tile = tile / variant id of that kernel; ksplit = K slices (kinds 0 / 4 / 5: + 1000 = slices combined inside the launch

@@ -2,9 +2,8 @@
 
   * tools/gen_wino1d.py's Toom-Cook matrices reproduce the correlation EXACTLY (rationals) for every 1-D kind the kernel has, and
     the committed header demon_amd/csrc/wino1d_tables.h is what the generator writes (nobody edited it by hand);
-  * the F(2,2) x F(2,2) form of the 4x4 stride-2 transposed conv (blocks_original.py:64-75) and the F(2x2,3x3) form of the 3x3
-    stride-1 conv (helpers.py:70-102), written out as the kernels do them (tap sums / G g Gt, row-then-column input transform,
-    output sums), equal PyTorch's conv_transpose2d / conv2d.
+  * the F(2,2) x F(2,2) form of the 4x4 stride-2 transposed conv (blocks_original.py:64-75), written out as the kernel does it
+    (tap sums, row-then-column input transform, output sums), equals PyTorch's conv_transpose2d.
 The GPU twins (tests/test_variants_gpu.py::test_minimal_filtering_*) hold the kernels themselves to PyTorch at 1e-5."""
 import importlib.util
 import os
@@ -86,27 +85,3 @@ def test_deconv_f22_form_equals_conv_transpose():
                             if y < H and xx < W:
                                 out[:, :, 2 * y + py, 2 * xx + px] = M[:, :, a, b] + M[:, :, a, b + 1] + M[:, :, a + 1, b] + M[:, :, a + 1, b + 1]
     np.testing.assert_allclose(out, ref, rtol=0, atol=1e-12)
-
-
-def test_conv3_f2x2_3x3_form_equals_conv2d():
-    """wino_conv3_kernel's arithmetic in numpy: U = G g Gt, T = Bt d B (rows first), Y = At (sum_ci U . T) A"""
-    import torch
-    import torch.nn.functional as F
-    rng = np.random.default_rng(4)
-    N, Cin, Cout, H, W = 2, 4, 3, 5, 6
-    x = rng.standard_normal((N, Cin, H, W))
-    w = rng.standard_normal((3, 3, Cin, Cout))   # HWIO
-    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(np.ascontiguousarray(w.transpose(3, 2, 0, 1))), padding=1).numpy()
-    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
-    BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], float)
-    AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], float)
-    U = np.einsum("ua,abio,vb->uvio", G, w, G)
-    xp = np.pad(x, ((0, 0), (0, 0), (1, 3), (1, 3)))
-    out = np.zeros((N, Cout, H + 1, W + 1))
-    for r in range((H + 1) // 2):
-        for c in range((W + 1) // 2):
-            d = xp[:, :, 2 * r:2 * r + 4, 2 * c:2 * c + 4]
-            T = np.einsum("uj,ncji,vi->ncuv", BT, d, BT)
-            M = np.einsum("uvio,niuv->nouv", U, T)
-            out[:, :, 2 * r:2 * r + 2, 2 * c:2 * c + 2] = np.einsum("au,nouv,bv->noab", AT, M, AT)
-    np.testing.assert_allclose(out[:, :, :H, :W], ref, rtol=0, atol=1e-12)

@@ -12,10 +12,6 @@ LAYERS = [("refine4 up 512->256 6x8", 512, 6, 8, 256), ("refine3 up 514->128 12x
           ("refine1 up 128->64 48x64", 128, 48, 64, 64), ("refine0 up 128->32 96x128", 128, 96, 128, 32)]
 
 
-CONV3 = [("rf conv1_1 64->64 96x128", 64, 96, 128, 64), ("rf conv2_1 128->128 48x64", 128, 48, 64, 128), ("predict2 conv1 130->24 48x64", 130, 48, 64, 24),
-         ("predict5 conv1 512->24 6x8", 512, 6, 8, 24)]
-
-
 CONV1D = [("conv2_1y 64->64 3x1 48x64", 64, 48, 64, 64, 3, 1, 1, 1), ("conv2_1x 64->64 1x3 48x64", 64, 48, 64, 64, 1, 3, 1, 1),
           ("conv3_1y 128->128 3x1 24x32", 128, 24, 32, 128, 3, 1, 1, 1), ("conv4_1x 256->256 1x3 12x16", 256, 12, 16, 256, 1, 3, 1, 1),
           ("conv5_1y 512->512 3x1 6x8", 512, 6, 8, 512, 3, 1, 1, 1),
@@ -30,7 +26,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--skip-deconv", action="store_true")
-    ap.add_argument("--skip-conv3", action="store_true")
     ap.add_argument("--only1d", default="", help="substring filter on the 1-D layer labels")
     args = ap.parse_args()
     ctx = DemonContext(0, 1)
@@ -61,34 +56,6 @@ def main():
                     wb = (ms, tf, ks)
             if wb:
                 line += " | wino v%d %.3f ms %5.1f TF/s k%d [%s]" % (v, wb[0], wb[1], wb[2], " ".join(allks))
-        print(line, flush=True)
-    # 3 x 3 stride-1 convs: best direct plan (automatic choice and the patch tiles) vs F(2x2,3x3)
-    for lab, cin, h, w, cout in ([] if args.skip_conv3 else CONV3):
-        line = "%-28s" % lab
-        best = None
-        for tile in (-1, 100, 101, 102, 103, 104, 106):
-            try:
-                ms, tf = ctx.bench_layer("conv", args.n, cin, h, w, cout, 3, 3, 1, 1, tile=tile, ksplit=0, iters=10)
-            except Exception:
-                continue
-            if best is None or ms < best[0]:
-                best = (ms, tf, tile)
-        line += " direct best %.3f ms %5.1f TF/s (t%d)" % best
-        for v in range(4):
-            wb = None
-            allks = []
-            for ks in (1, 2, 4):
-                try:
-                    ms, tf = ctx.bench_layer("conv", args.n, cin, h, w, cout, 3, 3, 1, 1, tile=400 + v, ksplit=ks, iters=10)
-                except Exception:
-                    continue
-                if not ctx.last_kernel().startswith("wino"):
-                    continue
-                allks.append("k%d:%.3f" % (ks, ms))
-                if wb is None or ms < wb[0]:
-                    wb = (ms, tf, ks)
-            if wb:
-                line += " | wino3 v%d %.3f ms %5.1f TF/s k%d [%s]" % (v, wb[0], wb[1], wb[2], " ".join(allks))
         print(line, flush=True)
     # separable layers: best direct plan vs 1-D minimal filtering
     for lab, cin, h, w, cout, kh, kw, sh, sw in CONV1D:
