@@ -56,11 +56,11 @@ def kernel_tag(name):
     m = re.search(r"wino_deconv_kernel<(\d+)", name)
     if m:
         return "wino_deconv<16x%d>" % (16 * int(m.group(1)))
-    m = re.search(r"wino1d_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
-    if m:
-        kind, axis, wm, wn, tn = map(int, m.groups())
+    m = re.search(r"wino1d_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
+    if m:   # (the 3 x 3 layers, tag "t3x3", run the 3-tap instance: the template name cannot tell them apart)
+        kind, axis, wm, wn, tn, kg = map(int, m.groups())
         shapes = {(2, 2, 2): 0, (4, 1, 4): 1, (2, 2, 4): 2, (4, 2, 4): 3}
-        return "wino1d<t%d,v%d>" % (3 if kind == 0 else 3 + 2 * kind, shapes.get((wm, wn, tn), -1))
+        return "wino1d<t%d,v%d>" % (3 if kind == 0 else 3 + 2 * kind, shapes.get((wm, wn, tn), -1) + 4 * (kg - 1))
     m = re.search(r"deconv4_kernel<(\d+), (\d+), (\d+)", name)
     if m:
         bm, wm, wn = map(int, m.groups())
