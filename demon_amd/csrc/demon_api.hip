@@ -84,6 +84,22 @@ struct Layer {
     static bool stream_shape_ok(Kind kind, int Cin, int kh, int kw) { return Cin % 16 == 0 && (kind != CONV || kh * kw <= 9); }
 };
 
+// The launch plan of a layer for batch n: the entry measured at exactly n, else the one of the NEAREST tuned batch size (by ratio) --
+// a ragged last batch inside a context tuned for its full batch (runtime.get_context installs one plan) keeps the tuned kernel
+// families and variants instead of falling back to the untuned heuristics; kernels clamp a split-K that does not fit.
+inline std::map<int, Layer::Tuned>::const_iterator nearest_tuned(const Layer *L, int n)
+{
+    auto it = L->tuned.find(n);
+    if (it != L->tuned.end() || L->tuned.empty()) return it;
+    auto best = L->tuned.begin();
+    double best_r = 1e30;
+    for (auto jt = L->tuned.begin(); jt != L->tuned.end(); ++jt) {
+        const double r = jt->first > n ? (double)jt->first / n : (double)n / jt->first;
+        if (r < best_r) { best_r = r; best = jt; }
+    }
+    return best;
+}
+
 struct Step {
     std::string name;
     std::string kernel;
@@ -771,8 +787,8 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
         }
     }
     if (L->force_tile < 0) {
-        auto it = L->tuned.find(n);
-        if (it != L->tuned.end()) {  // measured choice (demon_autotune)
+        auto it = nearest_tuned(L, n);
+        if (it != L->tuned.end()) {  // measured choice (demon_autotune), of this batch size or the nearest tuned one
             const Layer::Tuned &t = it->second;
             if (t.kind == 3 && small_applies(L)) {
                 run_small(L, a, s);
@@ -1027,7 +1043,7 @@ bool chain_choice(const Layer *Ly, const Layer *Lx, int n, int &kind, int &v)
         int ks = 0;
         if (sscanf(fp, "%d,%d,%d", &kind, &v, &ks) == 3) return (kind == 6 || kind == 7) && chain_shape_ok(Ly, Lx, kind, v);
     }
-    auto it = Ly->tuned.find(n);
+    auto it = nearest_tuned(Ly, n);
     if (it == Ly->tuned.end()) return false;
     kind = it->second.kind;
     v = it->second.tile;

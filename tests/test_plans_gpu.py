@@ -125,3 +125,24 @@ def test_config1_batch8_bootstrap_only():
                 assert rel_l1(got[k][i], want[k][i]) < 1e-3, (k, i)
     finally:
         ctx.close()
+
+
+def test_ragged_batch_keeps_the_tuned_plan():
+    """a last batch smaller than the context's (3 pairs in a context built and tuned for 8, as runtime.get_context sets one up)
+    runs on the plan entries of the nearest tuned batch size -- the minimal-filtering / streaming kernels of the batch-8 plan --
+    not on the untuned heuristics, and agrees with the oracle"""
+    from demon_amd import DemonContext
+    w = _weights(1, 192, 256)
+    ctx = DemonContext(0, 8, 192, 256)
+    try:
+        ctx.set_weights(w)
+        assert ctx.load_tuned_plan(8, nearest=False) == 8
+        pair, img2_2 = make_inputs(3, seed=83)
+        got = ctx.full(pair, img2_2, iterations=3)
+        tags = [r["kernel"] for r in ctx.profile_full(3, 3, 1)]
+        assert any(t.startswith("wino_deconv<") for t in tags) and any(t.startswith("wino1d<") for t in tags), sorted(set(tags))
+        want = net_ref.DemonRef(w).full(pair, img2_2, iterations=3)
+        for k in KEYS:
+            assert rel_l1(got[k], want[k]) < 1e-3, k
+    finally:
+        ctx.close()
