@@ -360,6 +360,11 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     using K = Wino1D<KIND>;
     constexpr int NUV = K::NUV, WIN = K::WIN, STRIDE = K::STRIDE;
     constexpr int NT = 64 * WM * WN, CKS = 4 * KG;
+    // stride-2 filters along x: the window of tile c starts at x = 4c - pad, so it lies inside the three 16-byte vectors [4c-4, 4c+8):
+    // three fully coalesced buffer_load_dwordx4 per unit instead of WIN 4-byte loads 16 bytes apart (needs W % 4 == 0: a vector is
+    // then entirely inside or entirely outside its image row)
+    constexpr bool VEC = AXIS == 1 && STRIDE == 2;
+    constexpr int NLD = VEC ? 3 : WIN, PWD = VEC ? 12 : WIN;
     constexpr int BM = 16 * WM, NTILE = 16 * TN * WN;
     constexpr int UNITS = KG * TN / WM;                // staging units (tile, channel) per thread: CKS * NTILE / NT
     constexpr int TP = NTILE + ((NTILE & 31) ? 0 : 16);   // row pitch of T: the k = 0 / 1 halves of a 32-lane LDS access on different banks
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
 
     // ---- staging units: unit i of this thread = (tile q, channel k).  a.cross > 1 (3 x 3 layers as three 1 x 3 filters whose products
     // add up in the same accumulators): the K-steps run over (cross tap ky, channel step); the load offsets are set per ky
-    int goff[UNITS][WIN], tw[2][UNITS], ur[UNITS], uc[UNITS], ub[UNITS];
+    int goff[UNITS][NLD], tw[2][UNITS], ur[UNITS], uc[UNITS], ub[UNITS];
     unsigned lastmask = 0;
     const int last_c0 = (a.csteps - 1) * CKS;
 #pragma unroll
@@ -410,9 +415,9 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
 #pragma unroll
         for (int i = 0; i < UNITS; ++i)
 #pragma unroll
-            for (int e = 0; e < WIN; ++e) {
+            for (int e = 0; e < NLD; ++e) {
                 const int gy = AXIS == 0 ? 2 * STRIDE * ur[i] - a.pad + e : ur[i] + ky - a.cross_pad;
-                const int gx = AXIS == 0 ? uc[i] + ky - a.cross_pad : 2 * STRIDE * uc[i] - a.pad + e;
+                const int gx = AXIS == 0 ? uc[i] + ky - a.cross_pad : (VEC ? 4 * uc[i] - 4 + 4 * e : 2 * STRIDE * uc[i] - a.pad + e);
                 const bool ok = (ub[i] >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
                 goff[i][e] = ok ? ub[i] + 4 * (gy * a.W + gx) : OOB;
             }
@@ -446,9 +451,9 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
 
     // global loads run TWO K-steps ahead (two register sets): step s on buffer s&1:
     //   loads of step s+2 | MFMAs of step s | transform + LDS stores of step s+1 (loaded during step s-1) | barrier
-    float pregA[UNITS][WIN], pregB[UNITS][WIN];
+    float pregA[UNITS][PWD], pregB[UNITS][PWD];
     floatx4 aregA[APER], aregB[APER];
-    auto load_tiles = [&](float (&preg)[UNITS][WIN], floatx4 (&areg)[APER], int step) {
+    auto load_tiles = [&](float (&preg)[UNITS][PWD], floatx4 (&areg)[APER], int step) {
         int ky = 0, cs = step;
         if (a.cross > 1) {   // (uniform) steps are issued in increasing order: the offsets change twice per kernel
             ky = step / a.csteps;
@@ -460,16 +465,36 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
 #pragma unroll
         for (int i = 0; i < UNITS; ++i)
 #pragma unroll
-            for (int e = 0; e < WIN; ++e) preg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][e], 0, 0));
+            for (int e = 0; e < NLD; ++e) {
+                if constexpr (VEC) {
+                    const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, goff[i][e], 0, 0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) preg[i][4 * e + j] = v[j];
+                } else {
+                    preg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][e], 0, 0));
+                }
+            }
 #pragma unroll
         for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
     };
-    auto transform_store = [&](const float (&preg)[UNITS][WIN], const floatx4 (&areg)[APER], int buf, int step) {
+    auto transform_store = [&](const float (&preg)[UNITS][PWD], const floatx4 (&areg)[APER], int buf, int step) {
         const bool last = MASK && (step % a.csteps) == a.csteps - 1;   // (uniform) channels past Cin become zeros
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
             float t[NUV];
-            K::input(preg[i], t);
+            if constexpr (VEC) {   // the window inside the 12 loaded values: first element at 4 - pad (pad = taps / 2, or (taps - 2) / 2 for 'same')
+                float d[WIN];
+                if (a.pad == K::TAPS / 2) {
+#pragma unroll
+                    for (int e = 0; e < WIN; ++e) d[e] = preg[i][4 - K::TAPS / 2 + e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < WIN; ++e) d[e] = preg[i][4 - (K::TAPS - 2) / 2 + e];
+                }
+                K::input(d, t);
+            } else {
+                K::input(preg[i], t);
+            }
             if constexpr (MASK) {
                 if (last) {
                     const bool dead = !((lastmask >> i) & 1u);
@@ -717,6 +742,10 @@ bool wino1d_variant_ok(int kind, int v)
 bool wino1d_plan_geometry(Wino1Args &a, int kind, int variant, int axis, int n)
 {
     if (!wino1d_variant_ok(kind, variant) || a.Mpad % wino1d_variant_bm(variant)) return false;
+    if (axis == 1 && kind >= 1) {   // stride-2 filters along x load 16-byte vectors
+        const int taps = 3 + 2 * kind;
+        if ((a.W & 3) || (a.pad != taps / 2 && a.pad != (taps - 2) / 2)) return false;
+    }
     const int ntile = wino1d_variant_ntile(variant);
     const int gh = axis == 0 ? (a.Ho + 1) / 2 : a.Ho, gw = axis == 0 ? a.Wo : (a.Wo + 1) / 2;
     double best = 1e30;

@@ -163,7 +163,7 @@ def test_minimal_filtering_deconv(gpu_ctx, shape):
 # (cin, cout, kh, kw, sh, sw, H, W)
 WINO1D_LAYERS = [(64, 64, 3, 1, 1, 1, 24, 32), (128, 128, 1, 3, 1, 1, 12, 16), (64, 128, 5, 1, 2, 1, 48, 64), (128, 128, 1, 5, 1, 2, 24, 64),
                  (32, 64, 7, 1, 2, 1, 24, 32), (32, 32, 1, 7, 1, 2, 12, 64), (32, 32, 1, 9, 1, 2, 12, 64), (16, 32, 9, 1, 2, 1, 48, 64),
-                 (18, 40, 3, 1, 1, 1, 7, 9), (30, 24, 1, 5, 1, 2, 5, 23), (20, 36, 7, 1, 2, 1, 17, 33), (256, 256, 3, 1, 1, 1, 12, 16), (34, 32, 1, 9, 1, 2, 9, 31),
+                 (18, 40, 3, 1, 1, 1, 7, 9), (30, 24, 1, 5, 1, 2, 5, 23), (20, 36, 7, 1, 2, 1, 17, 33), (256, 256, 3, 1, 1, 1, 12, 16), (34, 32, 1, 9, 1, 2, 9, 31), (34, 32, 1, 9, 1, 2, 9, 36), (30, 24, 1, 5, 1, 2, 5, 24), (32, 32, 1, 7, 1, 2, 6, 20),
                  (130, 24, 3, 3, 1, 1, 48, 64), (64, 16, 3, 3, 1, 1, 40, 72), (64, 64, 3, 3, 1, 1, 24, 32), (18, 40, 3, 3, 1, 1, 7, 9)]   # 3 x 3: three 1 x 3 filters
 
 
@@ -194,6 +194,9 @@ def test_minimal_filtering_1d(gpu_ctx, layer):
                 err = rel_l1(got, want)
                 assert err < 1e-5, "variant %d split %d (%s): rel L1 %.3e" % (v, ks, tag, err)
                 np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True))   # deterministic
-        assert ran >= 3, ran
+        if kh == 1 and sw == 2 and W % 4:   # stride-2 filters along x load 16-byte vectors: rows must be a multiple of 4 pixels, else the layer
+            assert ran == 0, ran            # stays on the direct kernels (checked above all the same: the forced plan falls back)
+        else:
+            assert ran >= 3, ran
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
