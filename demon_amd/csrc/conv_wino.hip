@@ -360,11 +360,12 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     using K = Wino1D<KIND>;
     constexpr int NUV = K::NUV, WIN = K::WIN, STRIDE = K::STRIDE;
     constexpr int NT = 64 * WM * WN, CKS = 4 * KG;
-    // stride-2 filters along x: the window of tile c starts at x = 4c - pad, so it lies inside the three 16-byte vectors [4c-4, 4c+8):
-    // three fully coalesced buffer_load_dwordx4 per unit instead of WIN 4-byte loads 16 bytes apart (needs W % 4 == 0: a vector is
-    // then entirely inside or entirely outside its image row)
-    constexpr bool VEC = AXIS == 1 && STRIDE == 2;
-    constexpr int NLD = VEC ? 3 : WIN, PWD = VEC ? 12 : WIN;
+    // filters along x: the window of tile c starts at x = 2 STRIDE c - pad, so it lies inside the three vectors of VW = 2 STRIDE pixels
+    // [2 STRIDE (c-1), 2 STRIDE (c+2)): three fully coalesced 8- / 16-byte buffer loads per unit instead of WIN 4-byte loads 8 / 16
+    // bytes apart (needs W % VW == 0: a vector is then entirely inside or entirely outside its image row)
+    constexpr int VW = AXIS == 1 ? 2 * STRIDE : 1;
+    constexpr bool VEC = VW > 1;
+    constexpr int NLD = VEC ? 3 : WIN, PWD = VEC ? 3 * VW : WIN;
     constexpr int BM = 16 * WM, NTILE = 16 * TN * WN;
     constexpr int UNITS = KG * TN / WM;                // staging units (tile, channel) per thread: CKS * NTILE / NT
     constexpr int TP = NTILE + ((NTILE & 31) ? 0 : 16);   // row pitch of T: the k = 0 / 1 halves of a 32-lane LDS access on different banks
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
 #pragma unroll
             for (int e = 0; e < NLD; ++e) {
                 const int gy = AXIS == 0 ? 2 * STRIDE * ur[i] - a.pad + e : ur[i] + ky - a.cross_pad;
-                const int gx = AXIS == 0 ? uc[i] + ky - a.cross_pad : (VEC ? 4 * uc[i] - 4 + 4 * e : 2 * STRIDE * uc[i] - a.pad + e);
+                const int gx = AXIS == 0 ? uc[i] + ky - a.cross_pad : (VEC ? VW * (uc[i] - 1 + e) : 2 * STRIDE * uc[i] - a.pad + e);
                 const bool ok = (ub[i] >= 0) & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
                 goff[i][e] = ok ? ub[i] + 4 * (gy * a.W + gx) : OOB;
             }
@@ -466,10 +467,15 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
         for (int i = 0; i < UNITS; ++i)
 #pragma unroll
             for (int e = 0; e < NLD; ++e) {
-                if constexpr (VEC) {
+                if constexpr (VW == 4) {
                     const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, goff[i][e], 0, 0));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) preg[i][4 * e + j] = v[j];
+                } else if constexpr (VW == 2) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prsrc, goff[i][e], 0, 0));
+                    preg[i][2 * e] = v[0];
+                    preg[i][2 * e + 1] = v[1];
                 } else {
                     preg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][e], 0, 0));
                 }
@@ -482,14 +488,14 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
             float t[NUV];
-            if constexpr (VEC) {   // the window inside the 12 loaded values: first element at 4 - pad (pad = taps / 2, or (taps - 2) / 2 for 'same')
+            if constexpr (VEC) {   // the window inside the 3 VW loaded values: first element at VW - pad (pad = taps / 2, or (taps - 2) / 2 for stride-2 'same')
                 float d[WIN];
-                if (a.pad == K::TAPS / 2) {
+                if (STRIDE == 1 || a.pad == K::TAPS / 2) {
 #pragma unroll
-                    for (int e = 0; e < WIN; ++e) d[e] = preg[i][4 - K::TAPS / 2 + e];
+                    for (int e = 0; e < WIN; ++e) d[e] = preg[i][VW - K::TAPS / 2 + e];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < WIN; ++e) d[e] = preg[i][4 - (K::TAPS - 2) / 2 + e];
+                    for (int e = 0; e < WIN; ++e) d[e] = preg[i][VW - (K::TAPS - 2) / 2 + e];
                 }
                 K::input(d, t);
             } else {
@@ -742,9 +748,9 @@ bool wino1d_variant_ok(int kind, int v)
 bool wino1d_plan_geometry(Wino1Args &a, int kind, int variant, int axis, int n)
 {
     if (!wino1d_variant_ok(kind, variant) || a.Mpad % wino1d_variant_bm(variant)) return false;
-    if (axis == 1 && kind >= 1) {   // stride-2 filters along x load 16-byte vectors
-        const int taps = 3 + 2 * kind;
-        if ((a.W & 3) || (a.pad != taps / 2 && a.pad != (taps - 2) / 2)) return false;
+    if (axis == 1) {   // filters along x load their windows as 8-byte (stride 1) / 16-byte (stride 2) vectors
+        const int taps = kind == 0 ? 3 : 3 + 2 * kind;
+        if (kind == 0 ? ((a.W & 1) || a.pad != 1) : ((a.W & 3) || (a.pad != taps / 2 && a.pad != (taps - 2) / 2))) return false;
     }
     const int ntile = wino1d_variant_ntile(variant);
     const int gh = axis == 0 ? (a.Ho + 1) / 2 : a.Ho, gw = axis == 0 ? a.Wo : (a.Wo + 1) / 2;

@@ -194,7 +194,7 @@ def test_minimal_filtering_1d(gpu_ctx, layer):
                 err = rel_l1(got, want)
                 assert err < 1e-5, "variant %d split %d (%s): rel L1 %.3e" % (v, ks, tag, err)
                 np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True))   # deterministic
-        if kh == 1 and sw == 2 and W % 4:   # stride-2 filters along x load 16-byte vectors: rows must be a multiple of 4 pixels, else the layer
+        if (kh == 1 or kh == 3 == kw) and W % (2 * sw):   # filters along x load 8- / 16-byte vectors: rows must be a multiple of 2 / 4 pixels, else the layer
             assert ran == 0, ran            # stays on the direct kernels (checked above all the same: the forced plan falls back)
         else:
             assert ran >= 3, ran
