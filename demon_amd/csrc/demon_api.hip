@@ -732,6 +732,28 @@ bool run_wino1d(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipS
     return true;
 }
 
+// weight-streaming dense layer (dense_stream.hip), plan kind 11: ksplit = K slices across workgroups (dense_reduce_kernel adds them)
+bool dense_stream_applies(const Layer *L)
+{
+    return L->kind == Layer::DENSE && L->in.H * L->in.W == 1 && L->out.H * L->out.W == 1 && !L->scale && dense_stream_geometry_ok(L->Cin, L->Mpad, 1);
+}
+
+bool run_dense_stream(const Layer *L, const ConvArgs &a, int ksplit, hipStream_t s)
+{
+    if (ksplit < 1) ksplit = 1;
+    while (ksplit > 1 && !dense_stream_geometry_ok(L->Cin, L->Mpad, ksplit)) --ksplit;
+    if (!dense_stream_geometry_ok(L->Cin, L->Mpad, ksplit)) return false;
+    DenseArgs d;
+    d.x = a.in; d.out = a.out; d.wp = a.wp; d.bias = a.bias; d.ws = a.ws;
+    d.N = a.N; d.K = L->Cin; d.Cout = L->Cout; d.Mpad = L->Mpad;
+    d.x_n_stride = a.in_n_stride; d.out_n_stride = a.out_n_stride;
+    d.act = a.act; d.ksplit = ksplit;
+    launch_dense_stream(d, s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "dense_stream<128x32>%s", split_suffix(ksplit, false));
+    g_last_kernel = g_kernel_tag;
+    return true;
+}
+
 void run_mfma(const ConvArgs &a_in, ConvPlan plan, int ncls, hipStream_t s)
 {
     ConvArgs a = a_in;
@@ -771,6 +793,8 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 }
             } else if (kind == 10) {
                 if (wino1d_applies(L) && run_wino1d(L, a, tile, clamp_split(ks % 1000), s)) return;
+            } else if (kind == 11) {
+                if (dense_stream_applies(L) && run_dense_stream(L, a, clamp_split(ks % 1000), s)) return;
             } else if (kind == 8) {
                 if (wino_applies(L) && tile >= 0 && tile < WINO_VARIANTS && run_wino(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 1) {
@@ -805,6 +829,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             }
             if (t.kind == 8 && wino_applies(L) && run_wino(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 10 && wino1d_applies(L) && run_wino1d(L, a, t.tile, clamp_split(t.ksplit), s)) return;
+            if (t.kind == 11 && dense_stream_applies(L) && run_dense_stream(L, a, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
                 const int tw = t.ksplit / 1000 - 1, ks = t.ksplit % 1000;
@@ -823,6 +848,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
         const int v = L->force_tile - 400;
         if (wino_applies(L) && v < WINO_VARIANTS && run_wino(L, a, v, clamp_split(L->force_split), s)) return;
         if (wino1d_applies(L) && v < WINO1D_VARIANTS && run_wino1d(L, a, v, clamp_split(L->force_split), s)) return;
+        if (dense_stream_applies(L) && v == 0 && run_dense_stream(L, a, clamp_split(L->force_split), s)) return;
     }
     if (L->force_tile >= 300 && L->force_tile < 400) {  // demon_bench_layer: fragment-tiled kernel variant force_tile - 300
         const int v = L->force_tile - 300;
@@ -929,6 +955,15 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
                 if (wgs * ks < 64) continue;
                 cands.push_back({10, v, ks});
             }
+        }
+    }
+    if (dense_stream_applies(L)) {
+        const long blocks = (long)(L->Mpad / 128) * ((n + 31) / 32);
+        for (int ks : {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 32, 36, 48, 64}) {
+            if (!dense_stream_geometry_ok(L->Cin, L->Mpad, ks)) continue;
+            if (ks > 1 && ((long)ks * L->Mpad * P > kSplitKWorkspaceFloats || blocks * ks > 4096)) continue;
+            if (blocks * ks < 64 && ks < 64) continue;
+            cands.push_back({11, 0, ks});
         }
     }
     if (wino_applies(L) && !getenv("DEMON_NO_WINO")) {
@@ -2173,8 +2208,9 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
     if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
     // kinds: 0 im2col, 1 patch-staged, 3 small-Cout, 4 streaming, 5 fragment-tiled, 6 / 7 = kind 5 / 4 chained with the 1 x k partner
     // 8 = minimal-filtering transposed conv, 10 = 1-D minimal filtering (conv_wino.hip); 9 = the removed F(2x2,3x3) kernel (docs/experiments)
-    if (kind < 0 || kind > 10 || kind == 2 || kind == 9 || tile < 0 ||
-        tile >= (kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
+    // 11 = weight-streaming dense layer (dense_stream.hip; tile 0)
+    if (kind < 0 || kind > 11 || kind == 2 || kind == 9 || tile < 0 ||
+        tile >= (kind == 11 ? 1 : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
@@ -2182,6 +2218,7 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             if (kind == 8 && !wino_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the minimal-filtering kernel applies to transposed convs only");
             if (kind == 10 && !wino1d_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "no 1-D minimal-filtering form for this layer");
+            if (kind == 11 && !dense_stream_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the weight-streaming kernel applies to dense layers only");
             if (kind == 4 && (!L->stream_ok() || L->Mpad % stream_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the streaming kernel does not apply to this layer");
             if (kind == 5 && (!L->stream_ok() || L->Mpad % frag_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the fragment-tiled kernel does not apply to this layer");
             if (kind == 6 || kind == 7) {

@@ -342,6 +342,21 @@ long wino1d_workgroups(const Wino1Args &a, int variant);
 void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, int cross, hipStream_t s);
 void launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream);
 
+// ---- weight-streaming dense layer at small batch (dense_stream.hip): dense5 (v2), motion_fc1 -----------------------------------------------
+struct DenseArgs {
+    const float *x;      // activations [N][x_n_stride], K consecutive floats per sample
+    float *out;          // [N][out_n_stride], Cout consecutive floats per sample
+    const float *wp;     // packed weights [K][Mpad]
+    const float *bias;   // [Mpad]
+    float *ws;           // split-K workspace [slice][Mpad][N]
+    int N, K, Cout, Mpad;
+    long x_n_stride, out_n_stride;
+    int act, ksplit;
+};
+bool dense_stream_geometry_ok(int K, int Mpad, int ksplit);
+long dense_stream_workgroups(const DenseArgs &a);
+void launch_dense_stream(const DenseArgs &a, hipStream_t stream);   // + dense_reduce_kernel when ksplit > 1
+
 // ---- tiny heads (conv_small.hip): VALU direct conv for Cout <= 4, fused motion tail -------------------------------------
 struct SmallConvArgs {
     const float *in;

@@ -104,6 +104,7 @@ int demon_autotune(demon_ctx *ctx, int n);
  *   8 minimal-filtering transposed conv (conv_wino.hip; tile = variant: 32 / 64 / 48 tiles per workgroup),
  *   10 1-D minimal filtering for k x 1 / 1 x k convs (3 taps stride 1; 5 / 7 / 9 taps stride 2) and 3 x 3 stride-1 convs as three
  *      1 x 3 filters (conv_wino.hip; tile = workgroup shape 0..7); 9 is not used (a removed experiment),
+ *   11 weight-streaming kernel for the dense layers (dense_stream.hip: dense5 of v2, motion_fc1; tile 0, ksplit = K slices),
  *        3 small-Cout VALU kernel, 4 register-streaming kernel (conv_stream.hip), 5 fragment-tiled kernel (conv_frag.hip),
  *        6 / 7 on the k x 1 layer of a stride-1 pair: the pair runs as ONE chained launch of conv_frag / conv_stream variant `tile`;
  *   tile = tile / variant id of that kernel; ksplit = K slices (kinds 0 / 4 / 5: + 1000 = slices combined inside the launch
@@ -241,7 +242,7 @@ int demon_op_dense(demon_ctx *ctx, float *out, const float *in, const float *w_i
 /* ---- tuning / diagnostics ----------------------------------------------------------------------------
  * Times one contraction layer (kind 0 conv, 1 transposed conv k4 s2, 2 dense) on device-resident random
  * data with hip events; tile < 0 / ksplit <= 0 select the automatic plan (tile 0..7 im2col tiles, 100 + t patch tiles,
- * 200 + v streaming-kernel variants, 300 + v fragment-tiled variants, 400 + v minimal-filtering transposed-conv variants).
+ * 200 + v streaming-kernel variants, 300 + v fragment-tiled variants, 400 + v minimal-filtering variants (transposed conv / k x 1, 1 x k, 3 x 3 conv) resp. 400 = the weight-streaming kernel on a dense layer).
  * Not on the reference's path. */
 int demon_bench_layer(demon_ctx *ctx, int kind, int n, int cin, int h, int w, int cout, int kh, int kw, int sh,
                       int sw, int tile, int ksplit, int iters, float *avg_ms, double *flops);

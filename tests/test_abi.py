@@ -97,6 +97,7 @@ def test_shipped_plans_are_well_formed():
     limits[6], limits[7] = limits[5], limits[4]
     limits[8] = int(re.search(r"WINO_VARIANTS\s*=\s*(\d+)", src).group(1))      # minimal-filtering transposed conv (conv_wino.hip)
     limits[10] = int(re.search(r"WINO1D_VARIANTS\s*=\s*(\d+)", src).group(1))   # 1-D minimal filtering; 9 is not a kernel
+    limits[11] = 1                                                               # weight-streaming dense layer (dense_stream.hip)
     files = sorted(glob.glob(os.path.join(root, "tuned", "plan_*.json")))
     assert files
     for f in files:
@@ -104,7 +105,7 @@ def test_shipped_plans_are_well_formed():
         assert d["plan"] and d["batch"] >= 1 and d["height"] % 32 == 0 and d["width"] % 32 == 0, f
         for name, (kind, tile, ks) in d["plan"].items():
             assert kind in limits and 0 <= tile < limits[kind] and ks >= 0, (f, name)
-            if kind in (0, 4, 5, 8, 10):
+            if kind in (0, 4, 5, 8, 10, 11):
                 assert 1 <= ks < 1000, (f, name)
             if kind in (6, 7):
                 assert name.endswith("y") and name[:-1] + "x" in d["plan"] and ks == 1, (f, name)
@@ -125,6 +126,7 @@ def test_kernel_names_round_trip():
         "void demon::wino_deconv_kernel<2, 4, 3>(demon::WinoArgs)": "wino_deconv<16x32>",
         "void demon::wino1d_kernel<1, 0, 2, 2, 2, 1, false>(demon::Wino1Args)": "wino1d<t5,v0>",
         "void demon::wino1d_kernel<0, 1, 4, 1, 4, 2, false>(demon::Wino1Args)": "wino1d<t3,v5>",
+        "demon::dense_stream_kernel(demon::DenseArgs)": "dense_stream<128x32>",
     }
     for name, tag in cases.items():
         assert kernel_tag(name) == tag

@@ -200,3 +200,36 @@ def test_minimal_filtering_1d(gpu_ctx, layer):
             assert ran >= 3, ran
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+# (batch, cin, cout)
+DENSE_LAYERS = [(32, 4608, 4608), (7, 6144, 1024), (1, 1024, 128), (33, 2048, 256), (64, 4608, 384), (5, 72, 128)]
+
+
+@pytest.mark.parametrize("layer", DENSE_LAYERS)
+def test_weight_streaming_dense(gpu_ctx, layer):
+    """dense_stream.hip (plan kind 11): dense5 of the v2 blocks (v2/blocks.py:197-213) and motion_fc1 (blocks_original.py:390-396) as
+    a weight stream -- weights global -> registers -> MFMA, 4 waves x K slices combined in a fixed order.  Against float64 numpy,
+    every split, batches that are not a multiple of the 32-sample MFMA block (and more than one block), K ranges that do not
+    divide evenly over waves and slices; two runs are bit-identical"""
+    n, cin, cout = layer
+    rng = np.random.default_rng(35)
+    x = rng.standard_normal((n, cin)).astype(np.float32)
+    w = (rng.standard_normal((cin, cout)) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    want = x.astype(np.float64) @ w.astype(np.float64) + b
+    want = np.where(want >= 0, want, 0.1 * want)
+    try:
+        for ks in (1, 2, 3, 5, 9, 16, 36, 64):
+            os.environ["DEMON_FORCE_PLAN"] = "11,0,%d" % ks
+            got = gpu_ctx.dense(x, w, b, lrelu=True)
+            tag = gpu_ctx.last_kernel()
+            assert tag.startswith("dense_stream<"), tag
+            err = rel_l1(got, want)
+            assert err < 1e-5, "split %d (%s): rel L1 %.3e" % (ks, tag, err)
+            np.testing.assert_array_equal(got, gpu_ctx.dense(x, w, b, lrelu=True))
+        os.environ["DEMON_FORCE_PLAN"] = "11,0,1"
+        got = gpu_ctx.dense(x, w, b, lrelu=False)   # no activation
+        assert rel_l1(got, x.astype(np.float64) @ w.astype(np.float64) + b) < 1e-5
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
