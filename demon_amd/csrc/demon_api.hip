@@ -62,6 +62,9 @@ struct Layer {
     // 1-D minimal filtering (conv_wino.hip): k x 1 / 1 x k layers with 3 taps stride 1 or 5 / 7 / 9 taps stride 2; U[e][Cin4][Mpad] in d_w1
     float *d_w1 = nullptr;
     mutable bool w1_dirty = true;
+    // weight-streaming dense kernel (dense_stream.hip): the weights re-blocked to [Mpad / 128][Cin][128]
+    float *d_wd = nullptr;
+    mutable bool wd_dirty = true;
     int wino1d_axis() const { return kw == 1 ? 0 : 1; }
     int wino1d_cross() const { return (kh == 3 && kw == 3) ? 3 : 1; }   // 3 x 3 stride 1: three 1 x 3 filters summed in the same accumulators
     int wino1d_kind_of() const
@@ -294,6 +297,12 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
         if (!L->d_w1 || hipMemset(L->d_w1, 0, sizeof(float) * nu) != hipSuccess) return false;
         L->w1_dirty = true;
     }
+    if (L->kind == Layer::DENSE && L->in.H * L->in.W == 1 && L->out.H * L->out.W == 1 && !L->scale && dense_stream_geometry_ok(L->Cin, L->Mpad, 1) &&
+        (long)L->Cin * L->Mpad >= (1l << 20)) {   // >= 4 MB of weights: below that a dense layer is launch bound whatever streams them
+        L->d_wd = dev_alloc(c, sizeof(float) * (size_t)L->Cin * L->Mpad);
+        if (!L->d_wd) return false;
+        L->wd_dirty = true;
+    }
     if (!alloc_weights) return true;  // network layers: alloc_weight_slab() places d_wp / d_bias once all layers exist
     L->d_wp = dev_alloc(c, sizeof(float) * (size_t)L->ncls * L->Krows * L->Mpad);
     L->d_bias = dev_alloc(c, sizeof(float) * L->Mpad);
@@ -356,6 +365,7 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
     L->have_kernel = true;
     L->wf_dirty = true;
     L->w1_dirty = true;
+    L->wd_dirty = true;
     return DEMON_OK;
 }
 
@@ -733,23 +743,25 @@ bool run_wino1d(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipS
 }
 
 // weight-streaming dense layer (dense_stream.hip), plan kind 11: ksplit = K slices across workgroups (dense_reduce_kernel adds them)
-bool dense_stream_applies(const Layer *L)
-{
-    return L->kind == Layer::DENSE && L->in.H * L->in.W == 1 && L->out.H * L->out.W == 1 && !L->scale && dense_stream_geometry_ok(L->Cin, L->Mpad, 1);
-}
+bool dense_stream_applies(const Layer *L) { return L->d_wd != nullptr; }
 
-bool run_dense_stream(const Layer *L, const ConvArgs &a, int ksplit, hipStream_t s)
+bool run_dense_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
 {
+    if (variant < 0 || variant >= DENSE_VARIANTS) return false;
+    if (L->wd_dirty) {
+        launch_dense_repack(L->d_wd, L->d_wp, L->Cin, L->Mpad, s);
+        L->wd_dirty = false;
+    }
     if (ksplit < 1) ksplit = 1;
     while (ksplit > 1 && !dense_stream_geometry_ok(L->Cin, L->Mpad, ksplit)) --ksplit;
     if (!dense_stream_geometry_ok(L->Cin, L->Mpad, ksplit)) return false;
     DenseArgs d;
-    d.x = a.in; d.out = a.out; d.wp = a.wp; d.bias = a.bias; d.ws = a.ws;
+    d.x = a.in; d.out = a.out; d.wd = L->d_wd; d.bias = a.bias; d.ws = a.ws;
     d.N = a.N; d.K = L->Cin; d.Cout = L->Cout; d.Mpad = L->Mpad;
     d.x_n_stride = a.in_n_stride; d.out_n_stride = a.out_n_stride;
     d.act = a.act; d.ksplit = ksplit;
-    launch_dense_stream(d, s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "dense_stream<128x32>%s", split_suffix(ksplit, false));
+    launch_dense_stream(d, variant, s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "dense_stream<128x32,v%d>%s", variant, split_suffix(ksplit, false));
     g_last_kernel = g_kernel_tag;
     return true;
 }
@@ -794,7 +806,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             } else if (kind == 10) {
                 if (wino1d_applies(L) && run_wino1d(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 11) {
-                if (dense_stream_applies(L) && run_dense_stream(L, a, clamp_split(ks % 1000), s)) return;
+                if (dense_stream_applies(L) && run_dense_stream(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 8) {
                 if (wino_applies(L) && tile >= 0 && tile < WINO_VARIANTS && run_wino(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 1) {
@@ -829,7 +841,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             }
             if (t.kind == 8 && wino_applies(L) && run_wino(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 10 && wino1d_applies(L) && run_wino1d(L, a, t.tile, clamp_split(t.ksplit), s)) return;
-            if (t.kind == 11 && dense_stream_applies(L) && run_dense_stream(L, a, clamp_split(t.ksplit), s)) return;
+            if (t.kind == 11 && dense_stream_applies(L) && run_dense_stream(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
                 const int tw = t.ksplit / 1000 - 1, ks = t.ksplit % 1000;
@@ -848,7 +860,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
         const int v = L->force_tile - 400;
         if (wino_applies(L) && v < WINO_VARIANTS && run_wino(L, a, v, clamp_split(L->force_split), s)) return;
         if (wino1d_applies(L) && v < WINO1D_VARIANTS && run_wino1d(L, a, v, clamp_split(L->force_split), s)) return;
-        if (dense_stream_applies(L) && v == 0 && run_dense_stream(L, a, clamp_split(L->force_split), s)) return;
+        if (dense_stream_applies(L) && v < DENSE_VARIANTS && run_dense_stream(L, a, v, clamp_split(L->force_split), s)) return;
     }
     if (L->force_tile >= 300 && L->force_tile < 400) {  // demon_bench_layer: fragment-tiled kernel variant force_tile - 300
         const int v = L->force_tile - 300;
@@ -963,7 +975,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
             if (!dense_stream_geometry_ok(L->Cin, L->Mpad, ks)) continue;
             if (ks > 1 && ((long)ks * L->Mpad * P > kSplitKWorkspaceFloats || blocks * ks > 4096)) continue;
             if (blocks * ks < 64 && ks < 64) continue;
-            cands.push_back({11, 0, ks});
+            for (int v = 0; v < DENSE_VARIANTS; ++v) cands.push_back({11, v, ks});
         }
     }
     if (wino_applies(L) && !getenv("DEMON_NO_WINO")) {
@@ -2031,7 +2043,7 @@ void slab_arrived(demon_ctx *c)
 {
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
-    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->w1_dirty = true; }
+    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->w1_dirty = true; L->wd_dirty = true; }
 }
 }  // namespace
 extern "C" {
@@ -2208,9 +2220,9 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
     if (!c || !layer_name || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad argument");
     // kinds: 0 im2col, 1 patch-staged, 3 small-Cout, 4 streaming, 5 fragment-tiled, 6 / 7 = kind 5 / 4 chained with the 1 x k partner
     // 8 = minimal-filtering transposed conv, 10 = 1-D minimal filtering (conv_wino.hip); 9 = the removed F(2x2,3x3) kernel (docs/experiments)
-    // 11 = weight-streaming dense layer (dense_stream.hip; tile 0)
+    // 11 = weight-streaming dense layer (dense_stream.hip; tile 0 / 1 = default / non-temporal weight loads)
     if (kind < 0 || kind > 11 || kind == 2 || kind == 9 || tile < 0 ||
-        tile >= (kind == 11 ? 1 : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
+        tile >= (kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {

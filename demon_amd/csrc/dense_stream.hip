@@ -5,7 +5,9 @@
 //
 //   * weights go global memory -> registers -> MFMA A operand, never through LDS: a lane loads 16 bytes = 4 consecutive output
 //     units of one weight row, and the 4 values feed 4 MFMAs (32x32x2) whose row r stands for unit 4 r + i -- the permutation of
-//     the output rows is undone at the store.  One load instruction of a wave covers 2 weight rows x 512 contiguous bytes.
+//     the output rows is undone at the store.  The weights are re-blocked once per weight update (dense_repack_kernel) to
+//     [128-unit column block][K][128]: what a wave streams is one contiguous run of memory, 1 KB per load instruction (two
+//     consecutive rows), 16 KB per chunk -- whole DRAM pages and TLB entries instead of 512-byte pieces 18 KB apart.
 //   * a wave owns a contiguous run of weight rows (K) of a 128-unit column block and walks it in chunks of 4 groups of 8 rows:
 //     16 loads of 16 bytes in flight per lane for the next chunk while the 64 MFMAs of the current one run (16 KB per wave,
 //     8 waves per CU: well above the bytes in flight that 8 TB/s need), no barrier on the weight path.
@@ -27,6 +29,9 @@ constexpr int DS_CHUNK_ROWS = 128;                    // rows of x staged per ch
 constexpr int DS_XBUF = DS_CHUNK_ROWS * DS_XP;        // floats of one x buffer
 constexpr int DS_LDS_FLOATS = 4 * 3 * 16 * 64;        // epilogue exchange (48 KB) >= the two x buffers (33 KB)
 
+// NT: non-temporal policy on the weight loads (every byte is read once per launch); MODE: 0 product, 1 / 2 diagnostic builds of the
+// loop (loads without MFMAs / MFMAs without loads) for tools/dense_probe.py
+template <bool NT, int MODE>
 __global__ __launch_bounds__(DS_NT, 2) void dense_stream_kernel(DenseArgs a)
 {
     __shared__ __attribute__((aligned(16))) float smem[DS_LDS_FLOATS];
@@ -51,16 +56,16 @@ __global__ __launch_bounds__(DS_NT, 2) void dense_stream_kernel(DenseArgs a)
     const int my_begin = wave == 0 ? seg_begin[0] : (wave == 1 ? seg_begin[1] : (wave == 2 ? seg_begin[2] : seg_begin[3]));
     const int my_cnt = wave == 0 ? seg_cnt[0] : (wave == 1 ? seg_cnt[1] : (wave == 2 ? seg_cnt[2] : seg_cnt[3]));
 
-    // ---- weights: lane (r = l31, h = lhi) of MFMA step t of group g reads row 8 g + 4 h + t, columns m0 + 4 r .. + 3
-    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp + (long)g_begin * 8 * a.Mpad + m0), 0, NREC, 0x00020000);
-    const int a_voff = 4 * (4 * lhi * a.Mpad + 4 * l31);
-    const int row_bytes = 4 * a.Mpad;
+    // ---- weights: lane (r = l31, h = lhi) of MFMA step t of group g reads row 8 g + 2 t + h, units 4 r .. 4 r + 3 of the block
+    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wd + ((long)blockIdx.x * a.K + (long)g_begin * 8) * DS_BM), 0, NREC, 0x00020000);
+    const int a_voff = 4 * (lhi * DS_BM + 4 * l31);
+    constexpr int row_bytes = 4 * DS_BM;
     // ---- activations: thread (n = tid / 8, q = tid % 8) loads x[n][32 p + 4 q .. + 3] of the 32-row segment p (= wave p's groups)
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long)n0 * a.x_n_stride + (long)g_begin * 8), 0, NREC, 0x00020000);
     const int xn = tid >> 3, xq = tid & 7;
     const int x_voff = (n0 + xn < a.N) ? 4 * (xn * (int)a.x_n_stride + 4 * xq) : OOB;
     const int xs_store = (4 * xq) * DS_XP + xn;               // + (32 p + e) * DS_XP
-    const int xs_read = (32 * wave + 4 * lhi) * DS_XP + l31;  // + (8 j + t) * DS_XP
+    const int xs_read = (32 * wave + lhi) * DS_XP + l31;      // + (8 j + 2 t) * DS_XP
 
     floatx16 acc[4];
 #pragma unroll
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(DS_NT, 2) void dense_stream_kernel(DenseArgs a)
             const int voff = g < my_cnt ? a_voff : OOB;   // (uniform) groups past the end: no memory traffic, zeros
             const int sbase = (my_begin + g) * 8 * row_bytes;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) buf[j * 4 + t] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff, sbase + t * row_bytes, 0));
+            for (int t = 0; t < 4; ++t) buf[j * 4 + t] = MODE == 2 ? floatx4{1.0f, 1.0f, 1.0f, 1.0f} : __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, voff, sbase + 2 * t * row_bytes, NT ? 2 : 0));
         }
     };
     auto compute = [&](const floatx4 (&buf)[16], int xbuf) {
@@ -100,9 +105,12 @@ __global__ __launch_bounds__(DS_NT, 2) void dense_stream_kernel(DenseArgs a)
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float b = xs[(8 * j + t) * DS_XP];
+                const float b = xs[(8 * j + 2 * t) * DS_XP];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[j * 4 + t][i], b, acc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    if (MODE == 1) acc[i][(j * 4 + t) & 15] += buf[j * 4 + t][i] * b;
+                    else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(buf[j * 4 + t][i], b, acc[i], 0, 0, 0);
+                }
             }
     };
 
@@ -166,50 +174,81 @@ __global__ __launch_bounds__(DS_NT, 2) void dense_stream_kernel(DenseArgs a)
     else finish(acc[3], 3);
 }
 
-// adds the K slices in slice order, bias, leaky relu; a workgroup turns a [64 units][32 samples] tile of the workspace (read as it
-// lies) into 32 runs of 64 consecutive units of the output (written as it lies).  grid: (Mpad / 64, ceil(N / 32))
+// adds the K slices in slice order, bias, leaky relu; a workgroup turns a [16 units][32 samples] tile of the workspace (read as it
+// lies) into 32 runs of 16 consecutive units of the output.  Four slices per round, so that a thread has 8 loads in flight: the
+// launch is a chain of memory latencies (ksplit / 4 of them), not a stream.  grid: (Mpad / 16, ceil(N / 32))
 __global__ __launch_bounds__(256) void dense_reduce_kernel(DenseArgs a)
 {
-    __shared__ float tile[64 * 33];
-    const int tid = threadIdx.x, m0 = blockIdx.x * 64, n0 = blockIdx.y * 32;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int e = tid + 256 * i, mm = e >> 5, nn = e & 31;
-        float v = 0.0f;
-        if (n0 + nn < a.N) {
-            const float *__restrict__ ws = a.ws + ((long)(m0 + mm)) * a.N + n0 + nn;
-            for (int z = 0; z < a.ksplit; ++z) v += ws[(long)z * a.Mpad * a.N];
-            v += a.bias[m0 + mm];   // (padded to Mpad)
-            if (a.act) v = v >= 0.0f ? v : 0.1f * v;
+    __shared__ float tile[16 * 33];
+    const int tid = threadIdx.x, m0 = blockIdx.x * 16, n0 = blockIdx.y * 32;
+    const int nn = tid & 31, mm = tid >> 5;   // this thread: units m0 + mm and m0 + mm + 8
+    const long stride = (long)a.Mpad * a.N;
+    float v0 = 0.0f, v1 = 0.0f;
+    if (n0 + nn < a.N) {
+        const float *__restrict__ p0 = a.ws + (long)(m0 + mm) * a.N + n0 + nn;
+        const float *__restrict__ p1 = p0 + 8l * a.N;
+        int z = 0;
+        for (; z + 4 <= a.ksplit; z += 4) {
+            const float a0 = p0[z * stride], a1 = p0[(z + 1) * stride], a2 = p0[(z + 2) * stride], a3 = p0[(z + 3) * stride];
+            const float b0 = p1[z * stride], b1 = p1[(z + 1) * stride], b2 = p1[(z + 2) * stride], b3 = p1[(z + 3) * stride];
+            v0 = (((v0 + a0) + a1) + a2) + a3;
+            v1 = (((v1 + b0) + b1) + b2) + b3;
         }
-        tile[mm * 33 + nn] = v;
+        for (; z < a.ksplit; ++z) { v0 += p0[z * stride]; v1 += p1[z * stride]; }
+        v0 += a.bias[m0 + mm];       // (padded to Mpad)
+        v1 += a.bias[m0 + mm + 8];
+        if (a.act) { v0 = v0 >= 0.0f ? v0 : 0.1f * v0; v1 = v1 >= 0.0f ? v1 : 0.1f * v1; }
     }
+    tile[mm * 33 + nn] = v0;
+    tile[(mm + 8) * 33 + nn] = v1;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int e = tid + 256 * i, nn = e >> 6, mm = e & 63;
-        if (n0 + nn < a.N && m0 + mm < a.Cout) a.out[(long)(n0 + nn) * a.out_n_stride + m0 + mm] = tile[mm * 33 + nn];
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i, on = e >> 4, om = e & 15;
+        if (n0 + on < a.N && m0 + om < a.Cout) a.out[(long)(n0 + on) * a.out_n_stride + m0 + om] = tile[om * 33 + on];
     }
 }
 
+// packed weights [K][Mpad] -> [Mpad / 128][K][128]; a thread moves 16 bytes
+__global__ __launch_bounds__(256) void dense_repack_kernel(float *__restrict__ wd, const float *__restrict__ wp, int K, int Mpad)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;   // float4 index in the destination
+    const long total = (long)K * Mpad / 4;
+    if (e >= total) return;
+    const int c4 = (int)(e & 31);
+    const long rk = e >> 5;
+    const int k = (int)(rk % K), mb = (int)(rk / K);
+    reinterpret_cast<floatx4 *>(wd)[e] = *reinterpret_cast<const floatx4 *>(wp + (long)k * Mpad + mb * DS_BM + c4 * 4);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------
+void launch_dense_repack(float *wd, const float *wp, int K, int Mpad, hipStream_t s)
+{
+    const long total = (long)K * Mpad / 4;
+    hipLaunchKernelGGL(dense_repack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wd, wp, K, Mpad);
+}
+
 bool dense_stream_geometry_ok(int K, int Mpad, int ksplit)
 {
     if (K < 64 || (K & 7) || (Mpad % DS_BM) || ksplit < 1 || ksplit > K / 32) return false;
     const long per_wg_rows = ((long)K + ksplit - 1) / ksplit + 8;
-    return per_wg_rows * Mpad * 4 < 0x3f000000l;   // 32-bit byte offsets inside a workgroup's slab of weights
+    return per_wg_rows * DS_BM * 4 < 0x3f000000l;   // 32-bit byte offsets inside a workgroup's slab of weights
 }
 
 long dense_stream_workgroups(const DenseArgs &a) { return (long)(a.Mpad / DS_BM) * a.ksplit * ((a.N + DS_BN - 1) / DS_BN); }
 
-void launch_dense_stream(const DenseArgs &a, hipStream_t stream)
+void launch_dense_stream(const DenseArgs &a, int variant, hipStream_t stream)
 {
     dim3 grid((unsigned)(a.Mpad / DS_BM), (unsigned)a.ksplit, (unsigned)((a.N + DS_BN - 1) / DS_BN));
-    hipLaunchKernelGGL(dense_stream_kernel, grid, dim3(DS_NT), 0, stream, a);
+    static const int mode = getenv("DEMON_DENSE_MODE") ? atoi(getenv("DEMON_DENSE_MODE")) : 0;   // tools/dense_probe.py
+    if (mode == 1) hipLaunchKernelGGL((dense_stream_kernel<false, 1>), grid, dim3(DS_NT), 0, stream, a);
+    else if (mode == 2) hipLaunchKernelGGL((dense_stream_kernel<false, 2>), grid, dim3(DS_NT), 0, stream, a);
+    else if (variant == 1) hipLaunchKernelGGL((dense_stream_kernel<true, 0>), grid, dim3(DS_NT), 0, stream, a);
+    else hipLaunchKernelGGL((dense_stream_kernel<false, 0>), grid, dim3(DS_NT), 0, stream, a);
     if (a.ksplit > 1) {
         // demon_profile_full times the reduce launch on its own (like conv_splitk_reduce)
         if (g_reduce_mark && hipEventRecord(g_reduce_mark, stream) == hipSuccess) g_reduce_marked = true;
-        dim3 rgrid((unsigned)(a.Mpad / 64), (unsigned)((a.N + 31) / 32));
+        dim3 rgrid((unsigned)(a.Mpad / 16), (unsigned)((a.N + 31) / 32));
         hipLaunchKernelGGL(dense_reduce_kernel, rgrid, dim3(256), 0, stream, a);
     }
 }

@@ -346,7 +346,7 @@ void launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStrea
 struct DenseArgs {
     const float *x;      // activations [N][x_n_stride], K consecutive floats per sample
     float *out;          // [N][out_n_stride], Cout consecutive floats per sample
-    const float *wp;     // packed weights [K][Mpad]
+    const float *wd;     // weights re-blocked to [Mpad / 128][K][128] (dense_repack_kernel)
     const float *bias;   // [Mpad]
     float *ws;           // split-K workspace [slice][Mpad][N]
     int N, K, Cout, Mpad;
@@ -355,7 +355,9 @@ struct DenseArgs {
 };
 bool dense_stream_geometry_ok(int K, int Mpad, int ksplit);
 long dense_stream_workgroups(const DenseArgs &a);
-void launch_dense_stream(const DenseArgs &a, hipStream_t stream);   // + dense_reduce_kernel when ksplit > 1
+constexpr int DENSE_VARIANTS = 2;   // 0: default cache policy on the weight loads, 1: non-temporal
+void launch_dense_repack(float *wd, const float *wp, int K, int Mpad, hipStream_t s);
+void launch_dense_stream(const DenseArgs &a, int variant, hipStream_t stream);   // + dense_reduce_kernel when ksplit > 1
 
 // ---- tiny heads (conv_small.hip): VALU direct conv for Cout <= 4, fused motion tail -------------------------------------
 struct SmallConvArgs {

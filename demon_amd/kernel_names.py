@@ -61,8 +61,9 @@ def kernel_tag(name):
         kind, axis, wm, wn, tn, kg = map(int, m.groups())
         shapes = {(2, 2, 2): 0, (4, 1, 4): 1, (2, 2, 4): 2, (4, 2, 4): 3}
         return "wino1d<t%d,v%d>" % (3 if kind == 0 else 3 + 2 * kind, shapes.get((wm, wn, tn), -1) + 4 * (kg - 1))
-    if "dense_stream_kernel" in name:
-        return "dense_stream<128x32>"
+    m = re.search(r"dense_stream_kernel<(true|false)", name)
+    if m:
+        return "dense_stream<128x32,v%d>" % (1 if m.group(1) == "true" else 0)
     m = re.search(r"deconv4_kernel<(\d+), (\d+), (\d+)", name)
     if m:
         bm, wm, wn = map(int, m.groups())

@@ -97,7 +97,7 @@ def test_shipped_plans_are_well_formed():
     limits[6], limits[7] = limits[5], limits[4]
     limits[8] = int(re.search(r"WINO_VARIANTS\s*=\s*(\d+)", src).group(1))      # minimal-filtering transposed conv (conv_wino.hip)
     limits[10] = int(re.search(r"WINO1D_VARIANTS\s*=\s*(\d+)", src).group(1))   # 1-D minimal filtering; 9 is not a kernel
-    limits[11] = 1                                                               # weight-streaming dense layer (dense_stream.hip)
+    limits[11] = 2                                                               # weight-streaming dense layer (dense_stream.hip)
     files = sorted(glob.glob(os.path.join(root, "tuned", "plan_*.json")))
     assert files
     for f in files:
@@ -126,7 +126,7 @@ def test_kernel_names_round_trip():
         "void demon::wino_deconv_kernel<2, 4, 3>(demon::WinoArgs)": "wino_deconv<16x32>",
         "void demon::wino1d_kernel<1, 0, 2, 2, 2, 1, false>(demon::Wino1Args)": "wino1d<t5,v0>",
         "void demon::wino1d_kernel<0, 1, 4, 1, 4, 2, false>(demon::Wino1Args)": "wino1d<t3,v5>",
-        "demon::dense_stream_kernel(demon::DenseArgs)": "dense_stream<128x32>",
+        "void demon::dense_stream_kernel<true, 0>(demon::DenseArgs)": "dense_stream<128x32,v1>",
     }
     for name, tag in cases.items():
         assert kernel_tag(name) == tag

@@ -203,7 +203,7 @@ def test_minimal_filtering_1d(gpu_ctx, layer):
 
 
 # (batch, cin, cout)
-DENSE_LAYERS = [(32, 4608, 4608), (7, 6144, 1024), (1, 1024, 128), (33, 2048, 256), (64, 4608, 384), (5, 72, 128)]
+DENSE_LAYERS = [(32, 4608, 4608), (7, 6144, 1024), (1, 8192, 128), (33, 4096, 256), (64, 4608, 384), (5, 8200, 128)]
 
 
 @pytest.mark.parametrize("layer", DENSE_LAYERS)
@@ -221,7 +221,7 @@ def test_weight_streaming_dense(gpu_ctx, layer):
     want = np.where(want >= 0, want, 0.1 * want)
     try:
         for ks in (1, 2, 3, 5, 9, 16, 36, 64):
-            os.environ["DEMON_FORCE_PLAN"] = "11,0,%d" % ks
+            os.environ["DEMON_FORCE_PLAN"] = "11,%d,%d" % (ks & 1, ks)   # variant 1 = non-temporal weight loads
             got = gpu_ctx.dense(x, w, b, lrelu=True)
             tag = gpu_ctx.last_kernel()
             assert tag.startswith("dense_stream<"), tag
