@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdemon_hip.so")
-SOURCES = ["demon_api.hip", "conv_mfma.hip", "conv_patch.hip", "conv_small.hip", "conv_pair.hip", "conv_stream.hip", "conv_frag.hip", "conv_wino.hip", "dense_stream.hip", "ops.hip"]
+SOURCES = ["demon_api.hip", "conv_mfma.hip", "conv_patch.hip", "conv_small.hip", "conv_pair.hip", "conv_stream.hip", "conv_frag.hip", "conv_wino.hip", "dense_stream.hip", "conv_thin.hip", "ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -167,6 +167,7 @@ struct demon_ctx {
     size_t w_slab_floats = 0;
     float *d_zero = nullptr;  // shared zero page of the conv_stream layers
     std::vector<std::pair<Layer *, Layer *>> chain_pairs;  // stride-1 k x 1 / 1 x k pairs that can run as one chained launch
+    std::vector<std::pair<Layer *, Layer *>> fused_pairs;  // pairs conv_pair.hip runs as one launch unless the plan of the k x 1 layer is kind 12
 };
 
 namespace {
@@ -766,6 +767,26 @@ bool run_dense_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit
     return true;
 }
 
+// the blocks' first layer with the weights in registers (conv_thin.hip), plan kind 12.  On the k x 1 layer of a pair that conv_pair.hip
+// can fuse, a kind-12 plan entry also means: run the pair as its two layers (demon_autotune measures both forms)
+bool thin_applies(const Layer *L)
+{
+    return L->kind == Layer::CONV && !L->scale && conv_thin_shape_ok(L->kh, L->kw, L->sh, L->sw, L->ph, L->pw, L->Cin, L->Mpad, L->in.W, L->out.W);
+}
+
+bool run_thin(const Layer *L, const ConvArgs &a, hipStream_t s)
+{
+    ThinArgs t;
+    t.in = a.in; t.out = a.out; t.wp = a.wp; t.bias = a.bias;
+    t.N = a.N; t.Cin = L->Cin; t.H = a.H; t.W = a.W; t.in_n_stride = a.in_n_stride;
+    t.Cout = L->Cout; t.Mpad = L->Mpad; t.Ho = a.Ho; t.Wo = a.Wo; t.out_n_stride = a.out_n_stride; t.out_plane = a.out_plane;
+    t.pad = L->ph; t.act = a.act; t.xcd = a.xcd; t.tiles_y = t.tiles_x = 0;
+    launch_conv_thin(t, s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_thin<32x512,t%d>", L->kh);
+    g_last_kernel = g_kernel_tag;
+    return true;
+}
+
 void run_mfma(const ConvArgs &a_in, ConvPlan plan, int ncls, hipStream_t s)
 {
     ConvArgs a = a_in;
@@ -805,6 +826,8 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 }
             } else if (kind == 10) {
                 if (wino1d_applies(L) && run_wino1d(L, a, tile, clamp_split(ks % 1000), s)) return;
+            } else if (kind == 12) {
+                if (thin_applies(L) && run_thin(L, a, s)) return;
             } else if (kind == 11) {
                 if (dense_stream_applies(L) && run_dense_stream(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 8) {
@@ -841,6 +864,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             }
             if (t.kind == 8 && wino_applies(L) && run_wino(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 10 && wino1d_applies(L) && run_wino1d(L, a, t.tile, clamp_split(t.ksplit), s)) return;
+            if (t.kind == 12 && thin_applies(L) && run_thin(L, a, s)) return;
             if (t.kind == 11 && dense_stream_applies(L) && run_dense_stream(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
@@ -861,6 +885,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
         if (wino_applies(L) && v < WINO_VARIANTS && run_wino(L, a, v, clamp_split(L->force_split), s)) return;
         if (wino1d_applies(L) && v < WINO1D_VARIANTS && run_wino1d(L, a, v, clamp_split(L->force_split), s)) return;
         if (dense_stream_applies(L) && v < DENSE_VARIANTS && run_dense_stream(L, a, v, clamp_split(L->force_split), s)) return;
+        if (thin_applies(L) && v == 0 && run_thin(L, a, s)) return;
     }
     if (L->force_tile >= 300 && L->force_tile < 400) {  // demon_bench_layer: fragment-tiled kernel variant force_tile - 300
         const int v = L->force_tile - 300;
@@ -969,6 +994,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
             }
         }
     }
+    if (thin_applies(L)) cands.push_back({12, 0, 1});
     if (dense_stream_applies(L)) {
         const long blocks = (long)(L->Mpad / 128) * ((n + 31) / 32);
         for (int ks : {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 32, 36, 48, 64}) {
@@ -1210,6 +1236,9 @@ struct Builder {
                 run_layer(Lx, n, s2, ws);
             };
         } else {
+            // plan kind 12 on the k x 1 layer (conv_thin.hip): the pair runs as its two layers, not as the fused launch
+            c->fused_pairs.push_back({Ly, Lx});
+            applies = [Ly](int n) { auto it = nearest_tuned(Ly, n); return !(it != Ly->tuned.end() && it->second.kind == 12 && thin_applies(Ly)); };
             st.fn = [Ly, Lx, ws](int n, hipStream_t s2) {
                 if (run_pair(Ly, Lx, n, s2)) return;
                 run_layer(Ly, n, s2, ws);
@@ -2177,6 +2206,54 @@ int autotune_chain(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
     return DEMON_OK;
 }
 
+// A pair conv_pair.hip can fuse whose k x 1 layer also has the weights-in-registers kernel (kind 12): one launch or two?  Measured
+// like autotune_layer does (a replayed hipGraph of five repetitions).  Two launches win: the k x 1 layer's plan becomes kind 12 (which
+// is what selects that form); the fused launch wins: it keeps / gets back its best other kernel.
+int autotune_fused_pair(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
+{
+    if (!thin_applies(Ly) || !c->opt_fused_pairs) return DEMON_OK;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;
+    bool failed = false;
+    auto measure = [&](bool fused) -> float {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            for (int i = 0; i < 5; ++i) {
+                if (fused && run_pair(Ly, Lx, n, c->stream)) continue;
+                run_layer(Ly, n, c->stream, c->d_ws);
+                run_layer(Lx, n, c->stream, c->d_ws);
+            }
+            ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        }
+        float ms = 1e30f;
+        if (ok) {
+            hipGraphLaunch(exec, c->stream);
+            hipEventRecord(e0, c->stream);
+            hipGraphLaunch(exec, c->stream);
+            hipEventRecord(e1, c->stream);
+            ok = hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        }
+        if (exec) hipGraphExecDestroy(exec);
+        if (graph) hipGraphDestroy(graph);
+        if (!ok) failed = true;
+        return ms;
+    };
+    const Layer::Tuned before = Ly->tuned.count(n) ? Ly->tuned[n] : Layer::Tuned{1, 0, 0};
+    Ly->tuned[n] = Layer::Tuned{12, 0, 1};
+    const float two = measure(false);
+    const float one = measure(true);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (failed) return DEMON_ERR_HIP;
+    if (one <= two) {
+        if (before.kind != 12) Ly->tuned[n] = before;
+        else Ly->tuned.erase(n);   // the fused launch wins and no other entry was measured: the heuristics serve the (unused) k x 1 layer
+    }
+    return DEMON_OK;
+}
+
 int demon_autotune(demon_ctx *c, int n)
 {
     if (!c || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "batch size out of range [1, max_batch]");
@@ -2195,6 +2272,11 @@ int demon_autotune(demon_ctx *c, int n)
     for (auto &pr : c->chain_pairs) {
         if (only && *only && pr.first->name.find(only) == std::string::npos) continue;
         int r = autotune_chain(c, pr.first, pr.second, n);
+        if (r) return fail(c, r, "autotune failed at pair " + pr.first->name);
+    }
+    for (auto &pr : c->fused_pairs) {
+        if (only && *only && pr.first->name.find(only) == std::string::npos) continue;
+        int r = autotune_fused_pair(c, pr.first, pr.second, n);
         if (r) return fail(c, r, "autotune failed at pair " + pr.first->name);
     }
     return DEMON_OK;
@@ -2221,8 +2303,9 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
     // kinds: 0 im2col, 1 patch-staged, 3 small-Cout, 4 streaming, 5 fragment-tiled, 6 / 7 = kind 5 / 4 chained with the 1 x k partner
     // 8 = minimal-filtering transposed conv, 10 = 1-D minimal filtering (conv_wino.hip); 9 = the removed F(2x2,3x3) kernel (docs/experiments)
     // 11 = weight-streaming dense layer (dense_stream.hip; tile 0 / 1 = default / non-temporal weight loads)
-    if (kind < 0 || kind > 11 || kind == 2 || kind == 9 || tile < 0 ||
-        tile >= (kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
+    // 12 = the blocks' first layer with the weights in registers (conv_thin.hip; tile 0); its pair then runs as two launches
+    if (kind < 0 || kind > 12 || kind == 2 || kind == 9 || tile < 0 ||
+        tile >= (kind == 12 ? 1 : kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
@@ -2230,6 +2313,7 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             if (kind == 8 && !wino_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the minimal-filtering kernel applies to transposed convs only");
             if (kind == 10 && !wino1d_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "no 1-D minimal-filtering form for this layer");
+            if (kind == 12 && !thin_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_thin.hip applies to the 9 x 1 stride-2 first layer (Cin <= 6, Cout <= 32) only");
             if (kind == 11 && !dense_stream_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the weight-streaming kernel applies to dense layers only");
             if (kind == 4 && (!L->stream_ok() || L->Mpad % stream_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the streaming kernel does not apply to this layer");
             if (kind == 5 && (!L->stream_ok() || L->Mpad % frag_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the fragment-tiled kernel does not apply to this layer");

@@ -359,6 +359,22 @@ constexpr int DENSE_VARIANTS = 2;   // 0: default cache policy on the weight loa
 void launch_dense_repack(float *wd, const float *wp, int K, int Mpad, hipStream_t s);
 void launch_dense_stream(const DenseArgs &a, int variant, hipStream_t stream);   // + dense_reduce_kernel when ksplit > 1
 
+// ---- the first layer of the blocks, a k x 1 conv over very few input channels with the weights in registers (conv_thin.hip) ------------
+struct ThinArgs {
+    const float *in;
+    float *out;
+    const float *wp;     // packed weights [tap * Cin + ci][Mpad]
+    const float *bias;
+    int N, Cin, H, W;
+    long in_n_stride;
+    int Cout, Mpad, Ho, Wo;
+    long out_n_stride, out_plane;
+    int pad, act, xcd;
+    int tiles_y, tiles_x;   // (set by the launcher)
+};
+bool conv_thin_shape_ok(int kh, int kw, int sh, int sw, int ph, int pw, int Cin, int Mpad, int W, int Wo);
+void launch_conv_thin(ThinArgs a, hipStream_t stream);
+
 // ---- tiny heads (conv_small.hip): VALU direct conv for Cout <= 4, fused motion tail -------------------------------------
 struct SmallConvArgs {
     const float *in;

@@ -61,6 +61,9 @@ def kernel_tag(name):
         kind, axis, wm, wn, tn, kg = map(int, m.groups())
         shapes = {(2, 2, 2): 0, (4, 1, 4): 1, (2, 2, 4): 2, (4, 2, 4): 3}
         return "wino1d<t%d,v%d>" % (3 if kind == 0 else 3 + 2 * kind, shapes.get((wm, wn, tn), -1) + 4 * (kg - 1))
+    m = re.search(r"conv_thin_kernel<(\d+)", name)
+    if m:
+        return "conv_thin<32x512,t%s>" % m.group(1)
     m = re.search(r"dense_stream_kernel<(true|false)", name)
     if m:
         return "dense_stream<128x32,v%d>" % (1 if m.group(1) == "true" else 0)

@@ -233,3 +233,32 @@ def test_weight_streaming_dense(gpu_ctx, layer):
         assert rel_l1(got, x.astype(np.float64) @ w.astype(np.float64) + b) < 1e-5
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+# (cin, cout, H, W)
+THIN_LAYERS = [(6, 32, 192, 256), (6, 24, 96, 128), (6, 32, 50, 68), (3, 32, 34, 64), (5, 17, 18, 200)]
+
+
+@pytest.mark.parametrize("layer", THIN_LAYERS)
+def test_first_layer_weights_in_registers(gpu_ctx, layer):
+    """conv_thin.hip (plan kind 12): the 9 x 1 stride-(2,1) conv over the <= 6 channels of image_pair (blocks_original.py:141, :331 via
+    helpers.py:105-153) with the whole reduction in registers.  Against PyTorch; image borders, partial row / column tiles, fewer
+    input / output channels than the tile holds"""
+    cin, cout, H, W = layer
+    rng = np.random.default_rng(36)
+    n = 3
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((9, 1, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("conv", x, w, b, (2, 1))
+    try:
+        os.environ["DEMON_FORCE_PLAN"] = "12,0,1"
+        got = gpu_ctx.conv2d(x, w, b, (2, 1), lrelu=True)
+        assert gpu_ctx.last_kernel().startswith("conv_thin<"), gpu_ctx.last_kernel()
+        assert got.shape == want.shape
+        assert rel_l1(got, want) < 1e-5
+        np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (2, 1), lrelu=True))
+        lin = gpu_ctx.conv2d(x, w, b, (2, 1), lrelu=False)   # without the activation: the same sums
+        np.testing.assert_array_equal(np.where(lin >= 0, lin, np.float32(0.1) * lin), got)
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
