@@ -515,18 +515,44 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
 #pragma unroll
         for (int i = 0; i < APER; ++i) *reinterpret_cast<floatx4 *>(smem + aw[buf][i]) = areg[i];
     };
+    // The LDS reads of a group of MFMAs are issued one group (>= 4 MFMAs = 128 cycles) before it: left to itself the compiler reads
+    // two operands, waits for them, issues their two MFMAs, reads the next two ... -- with one or two waves per SIMD (the deep,
+    // small maps) the matrix pipe then idles for an LDS latency after every pair.  The scheduling barriers pin LDS and MFMA
+    // instructions to the written order; vector-ALU, scalar and global-memory instructions may still move across them.
+    constexpr int EG = TN >= 4 ? 1 : 4 / TN;             // (K group, e) items per MFMA group
+    constexpr int NI = KG * NUV, NGRP = (NI + EG - 1) / EG;
+    constexpr bool PIPE = NUV * TN * 4 + 2 * UNITS * PWD <= 150;   // (the one shape whose registers are full reads each group just in time)
     auto compute = [&](int buf) {
         const float *A = smem + ra[buf];
         const float *T = smem + rt[buf];
+        float af[2][EG], tf[2][EG][TN];
+        auto fetch = [&](int g, int set) {
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg)
+            for (int j = 0; j < EG; ++j) {
+                const int it = g * EG + j;
+                if (it >= NI) continue;
+                const int kg = it / NUV, e = it - kg * NUV;
+                af[set][j] = A[e * (WM * 16 * CKS) + kg * 64];
 #pragma unroll
-            for (int e = 0; e < NUV; ++e) {
-                const float af = A[e * (WM * 16 * CKS) + kg * 64];
-#pragma unroll
-                for (int tb = 0; tb < TN; ++tb)
-                    acc[tb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, T[(e * CKS + kg * 4) * TP + tb * 16], acc[tb][e], 0, 0, 0);
+                for (int tb = 0; tb < TN; ++tb) tf[set][j][tb] = T[(e * CKS + kg * 4) * TP + tb * 16];
             }
+        };
+        if (PIPE) fetch(0, 0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            if (!PIPE) fetch(g, g & 1);
+            else if (g + 1 < NGRP) fetch(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0x16);
+#pragma unroll
+            for (int j = 0; j < EG; ++j) {
+                const int it = g * EG + j;
+                if (it >= NI) continue;
+                const int e = it % NUV;
+#pragma unroll
+                for (int tb = 0; tb < TN; ++tb) acc[tb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g & 1][j], tf[g & 1][j][tb], acc[tb][e], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0x16);
+        }
     };
 
     const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
@@ -697,7 +723,7 @@ static void launch_wino_ept(const WinoArgs &a, dim3 grid, size_t lds, hipStream_
     if (per_thread <= 2) hipLaunchKernelGGL((wino_deconv_kernel<TN, 2, OCC>), grid, dim3(WINO_NT), lds, s, a);
     else if (per_thread <= 4) hipLaunchKernelGGL((wino_deconv_kernel<TN, 4, OCC>), grid, dim3(WINO_NT), lds, s, a);
     else if (per_thread <= 6) hipLaunchKernelGGL((wino_deconv_kernel<TN, 6, OCC>), grid, dim3(WINO_NT), lds, s, a);
-    else hipLaunchKernelGGL((wino_deconv_kernel<TN, 8, OCC>), grid, dim3(WINO_NT), lds, s, a);
+    else hipLaunchKernelGGL((wino_deconv_kernel<TN, 8, (OCC > 1 && TN != 3 ? OCC - 1 : OCC)>), grid, dim3(WINO_NT), lds, s, a);   // 8 staged elements per thread: one wave per SIMD less, no spills
 }
 
 void launch_wino_deconv(const WinoArgs &a, int variant, hipStream_t stream)
