@@ -120,7 +120,8 @@ __global__ __launch_bounds__(TH_NT, 4) void conv_thin_kernel(ThinArgs a)
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 bool conv_thin_shape_ok(int kh, int kw, int sh, int sw, int ph, int pw, int Cin, int Mpad, int W, int Wo)
 {
-    return kh == 9 && kw == 1 && sh == 2 && sw == 1 && ph == 4 && pw == 0 && Cin >= 1 && Cin * 9 <= 56 && Mpad == 32 && W == Wo && (W & 3) == 0;
+    return kh == 9 && kw == 1 && sh == 2 && sw == 1 && ph >= 0 && ph <= 4 && pw == 0 &&   // ph 4: caffe padding, 3: 'same' (v2)
+           Cin >= 1 && Cin * 9 <= 56 && Mpad == 32 && W == Wo && (W & 3) == 0;
 }
 
 void launch_conv_thin(ThinArgs a, hipStream_t stream)
