@@ -355,7 +355,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
 // KG: MFMA K groups (of 4 input channels) per K-step, i.e. per barrier.  MASK: Cin is not a multiple of 4 KG -- the channels of the
 // last K-step that do not exist are replaced by zeros (costs NUV selects per step)
 template <int KIND, int AXIS, int WM, int WN, int TN, int KG, bool MASK>
-__global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG == 1 ? 64 : 32) && WM * WN <= 4) ? 3 : 2) void wino1d_kernel(Wino1Args a)
+__global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG == 1 ? 64 : (KG == 2 ? 32 : 0)) && WM * WN <= 4) ? 3 : 2) void wino1d_kernel(Wino1Args a)
 {
     using K = Wino1D<KIND>;
     constexpr int NUV = K::NUV, WIN = K::WIN, STRIDE = K::STRIDE;
@@ -372,9 +372,10 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     constexpr int ASZ = NUV * CKS * BM, TSZ = NUV * CKS * TP;
     constexpr int A4 = NUV * BM * KG;                  // 16-byte chunks of the weight tile
     constexpr int APER = (A4 + NT - 1) / NT;
-    static_assert(TN % WM == 0 && UNITS >= 1, "bad shape");
+    static_assert((KG * TN) % WM == 0 && UNITS >= 1, "bad shape");
     constexpr int OOB = 0x7ffffff0, NREC = 0x40000000;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // As[2][ASZ], Ts[2][TSZ], one dummy 16-byte slot per thread
+    TlScope tl(a.tl);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     // two operands, waits for them, issues their two MFMAs, reads the next two ... -- with one or two waves per SIMD (the deep,
     // small maps) the matrix pipe then idles for an LDS latency after every pair.  The scheduling barriers pin LDS and MFMA
     // instructions to the written order; vector-ALU, scalar and global-memory instructions may still move across them.
-    constexpr int EG = TN >= 4 ? 1 : 4 / TN;             // (K group, e) items per MFMA group
+    constexpr int EG = TN >= 4 ? 1 : (TN == 3 ? 2 : 4 / TN);   // (K group, e) items per MFMA group
     constexpr int NI = KG * NUV, NGRP = (NI + EG - 1) / EG;
     constexpr bool PIPE = NUV * TN * 4 + 2 * UNITS * PWD <= 150;   // (the one shape whose registers are full reads each group just in time)
     auto compute = [&](int buf) {
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
         transform_store(pregA, aregA, 0, phys(0));
     }
     __syncthreads();
+    tl.mark(1);
     {
         int s = 0;
         for (; s + 2 < nsteps; s += 2) {
@@ -586,6 +588,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
             compute(0);
         }
     }
+    tl.mark(2);
 
     // ---- epilogue: the two outputs of a tile from its NUV accumulators; lane = tile, registers = 4 consecutive channels.
     // Stores go through a buffer resource on this workgroup's corner of the output (uniform 64-bit base, 32-bit offsets per lane):
@@ -749,9 +752,12 @@ int wino1d_kind(int taps, int stride)
     return -1;
 }
 int wino1d_nuv(int kind) { return kind == 0 ? 4 : 5 + 2 * kind; }
-struct W1Shape { int wm, wn, tn; };
-static const W1Shape kW1Shapes[WINO1D_VARIANTS] = {{2, 2, 2}, {4, 1, 4}, {2, 2, 4}, {4, 2, 4}, {2, 2, 2}, {4, 1, 4}, {2, 2, 4}, {4, 2, 4}};
-int wino1d_variant_kg(int v) { return v >= 4 ? 2 : 1; }
+struct W1Shape { int wm, wn, tn, kg; };
+// 8..10: 48 / 96 tiles per workgroup -- the maps of this net are 3 * 2^k rows high (6 x 8, 12 x 16, 24 x 32 ...), so whole images fit
+// a 48- or 96-tile workgroup exactly where the 64-tile shapes leave a quarter of their tile slots empty (6 x 8: 24 tiles per image)
+static const W1Shape kW1Shapes[WINO1D_VARIANTS] = {{2, 2, 2, 1}, {4, 1, 4, 1}, {2, 2, 4, 1}, {4, 2, 4, 1}, {2, 2, 2, 2}, {4, 1, 4, 2}, {2, 2, 4, 2}, {4, 2, 4, 2},
+                                                   {4, 1, 3, 4}, {2, 2, 3, 2}, {4, 2, 3, 4}};
+int wino1d_variant_kg(int v) { return kW1Shapes[v].kg; }
 int wino1d_variant_bm(int v) { return 16 * kW1Shapes[v].wm; }
 int wino1d_variant_ntile(int v) { return 16 * kW1Shapes[v].tn * kW1Shapes[v].wn; }
 
@@ -766,7 +772,8 @@ bool wino1d_variant_ok(int kind, int v)
 {
     if (kind < 0 || v < 0 || v >= WINO1D_VARIANTS) return false;
     // accumulators: NUV x TN x 4 registers per lane; two K groups per step (variants 4..7) double the staging registers: kinds 0 / 1 only
-    if (wino1d_variant_kg(v) == 2 && (kind > 1 || (kind == 1 && kW1Shapes[v].tn > 2))) return false;   // (register budget)
+    if (wino1d_variant_kg(v) == 2 && (kind > 1 || (kind == 1 && kW1Shapes[v].tn > 3))) return false;   // (register budget)
+    if (wino1d_variant_kg(v) == 4 && kind != 0) return false;                                            // (LDS: 16 channels x NUV per step)
     return wino1d_nuv(kind) * kW1Shapes[v].tn * 4 <= 112 && wino1d_lds_bytes(kind, v) <= 160 * 1024;
 }
 
@@ -774,6 +781,7 @@ bool wino1d_variant_ok(int kind, int v)
 bool wino1d_plan_geometry(Wino1Args &a, int kind, int variant, int axis, int n)
 {
     if (!wino1d_variant_ok(kind, variant) || a.Mpad % wino1d_variant_bm(variant)) return false;
+    if (kind == 1 && axis == 1 && kW1Shapes[variant].tn == 3) return false;   // (register budget: 16-byte window vectors x 3 units x 2 sets)
     if (axis == 1) {   // filters along x load their windows as 8-byte (stride 1) / 16-byte (stride 2) vectors
         const int taps = kind == 0 ? 3 : 3 + 2 * kind;
         if (kind == 0 ? ((a.W & 1) || a.pad != 1) : ((a.W & 3) || (a.pad != taps / 2 && a.pad != (taps - 2) / 2))) return false;
@@ -836,7 +844,7 @@ static void launch_w1m(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
 template <int KIND, int AXIS, int WM, int WN, int TN, int KG>
 static void launch_w1(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    if constexpr (Wino1D<KIND>::NUV * TN * 4 <= 112 && (KG == 1 || KIND == 0 || (KIND == 1 && TN <= 2))) {
+    if constexpr (Wino1D<KIND>::NUV * TN * 4 <= 112 && (KG == 1 || KIND == 0 || (KIND == 1 && KG == 2 && TN <= 3)) && !(KIND == 1 && AXIS == 1 && TN == 3)) {
         if (a.Cin % (4 * KG)) launch_w1m<KIND, AXIS, WM, WN, TN, KG, true>(a, grid, lds, s);
         else launch_w1m<KIND, AXIS, WM, WN, TN, KG, false>(a, grid, lds, s);
     }
@@ -853,7 +861,10 @@ static void launch_w1_variant(const Wino1Args &a, int variant, dim3 grid, size_t
         case 4: launch_w1<KIND, AXIS, 2, 2, 2, 2>(a, grid, lds, s); break;
         case 5: launch_w1<KIND, AXIS, 4, 1, 4, 2>(a, grid, lds, s); break;
         case 6: launch_w1<KIND, AXIS, 2, 2, 4, 2>(a, grid, lds, s); break;
-        default: launch_w1<KIND, AXIS, 4, 2, 4, 2>(a, grid, lds, s); break;
+        case 7: launch_w1<KIND, AXIS, 4, 2, 4, 2>(a, grid, lds, s); break;
+        case 8: launch_w1<KIND, AXIS, 4, 1, 3, 4>(a, grid, lds, s); break;
+        case 9: launch_w1<KIND, AXIS, 2, 2, 3, 2>(a, grid, lds, s); break;
+        default: launch_w1<KIND, AXIS, 4, 2, 3, 4>(a, grid, lds, s); break;
     }
 }
 

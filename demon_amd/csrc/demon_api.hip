@@ -713,7 +713,7 @@ bool fill_wino1d_args(const Layer *L, const ConvArgs &a, int variant, Wino1Args 
     w.in = a.in; w.out = a.out; w.wu = L->d_w1; w.bias = a.bias; w.ws = a.ws;
     w.N = a.N; w.Cin = L->Cin; w.Cin4 = L->Cin4(); w.H = a.H; w.W = a.W; w.Ho = a.Ho; w.Wo = a.Wo; w.in_n_stride = a.in_n_stride;
     w.Cout = L->Cout; w.Mpad = L->Mpad; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
-    w.act = a.act; w.xcd = a.xcd;
+    w.act = a.act; w.xcd = a.xcd; w.tl = a.tl;
     w.pad = L->wino1d_axis() == 0 ? L->ph : L->pw;
     const int cks = 4 * wino1d_variant_kg(variant);
     w.cross = L->wino1d_cross();

@@ -330,8 +330,9 @@ struct Wino1Args {
     int G, TY, TX, tiles_y, tiles_x;     // workgroup tile = G images x TY x TX tiles (a tile = 2 outputs along the filter axis)
     int xcd;
     unsigned m_tytx, m_tx, m_tilesx, m_tilesy;
+    unsigned long long *tl;   // timeline records (diagnostic build), else null
 };
-constexpr int WINO1D_VARIANTS = 8;   // (WM x WN waves, TN tile blocks): 2x2x2, 4x1x4, 2x2x4, 4x2x4 with one (0..3) or two (4..7) K groups per step
+constexpr int WINO1D_VARIANTS = 11;   // workgroup shapes (waves along Cout x waves along tiles x tile blocks per wave x K groups per step)
 int wino1d_variant_kg(int v);
 int wino1d_kind(int taps, int stride);   // -1: no minimal-filtering form built for this filter
 int wino1d_nuv(int kind);

@@ -103,7 +103,7 @@ int demon_autotune(demon_ctx *ctx, int n);
  *   kind 0 im2col kernel (conv_mfma.hip), 1 patch-staged kernel (conv_patch.hip; ksplit + 1000 * (pixel-tile shape + 1)),
  *   8 minimal-filtering transposed conv (conv_wino.hip; tile = variant: 32 / 64 / 48 tiles per workgroup),
  *   10 1-D minimal filtering for k x 1 / 1 x k convs (3 taps stride 1; 5 / 7 / 9 taps stride 2) and 3 x 3 stride-1 convs as three
- *      1 x 3 filters (conv_wino.hip; tile = workgroup shape 0..7); 9 is not used (a removed experiment),
+ *      1 x 3 filters (conv_wino.hip; tile = workgroup shape 0..10); 9 is not used (a removed experiment),
  *   11 weight-streaming kernel for the dense layers (dense_stream.hip: dense5 of v2, motion_fc1; tile 0 / 1 = default /
  *      non-temporal weight loads, ksplit = K slices), 12 the blocks' first layer (9 x 1, stride 2, <= 6 input channels) with the weights
  *      in registers (conv_thin.hip; tile 0) -- on that layer it also means: the conv1 pair runs as two launches, not as conv_pair.hip's one,

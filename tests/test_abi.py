@@ -127,6 +127,8 @@ def test_kernel_names_round_trip():
         "void demon::wino_deconv_kernel<2, 4, 3>(demon::WinoArgs)": "wino_deconv<16x32>",
         "void demon::wino1d_kernel<1, 0, 2, 2, 2, 1, false>(demon::Wino1Args)": "wino1d<t5,v0>",
         "void demon::wino1d_kernel<0, 1, 4, 1, 4, 2, false>(demon::Wino1Args)": "wino1d<t3,v5>",
+        "void demon::wino1d_kernel<0, 0, 4, 1, 3, 4, false>(demon::Wino1Args)": "wino1d<t3,v8>",
+        "void demon::wino1d_kernel<1, 0, 2, 2, 3, 2, true>(demon::Wino1Args)": "wino1d<t5,v9>",
         "void demon::dense_stream_kernel<true, 0>(demon::DenseArgs)": "dense_stream<128x32,v1>",
         "void demon::conv_thin_kernel<9, 2, 14>(demon::ThinArgs)": "conv_thin<32x512,t9>",
     }

@@ -55,7 +55,7 @@ def test_all_variants_agree(gpu_ctx, layer):
     # split-K combined inside the launch (ksplit + 1000: tickets instead of the reduce launch)
     plans += [(0, t, ks) for t in range(8) for ks in (1002, 1005)] + [(4, v, 1003) for v in range(18)] + [(5, v, 1003) for v in range(22)]
     plans += [(8, v, ks) for v in range(4) for ks in (1, 2, 3)]   # minimal-filtering transposed conv (conv_wino.hip; Cin >= 16)
-    plans += [(10, v, ks) for v in range(8) for ks in (1, 2)]     # 1-D minimal filtering (3 taps stride 1; 5 / 7 / 9 taps stride 2)
+    plans += [(10, v, ks) for v in range(11) for ks in (1, 2)]     # 1-D minimal filtering (3 taps stride 1; 5 / 7 / 9 taps stride 2)
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
@@ -183,7 +183,7 @@ def test_minimal_filtering_1d(gpu_ctx, layer):
     want = _ref("conv", x, w, b, (sh, sw))
     ran = 0
     try:
-        for v in range(8):
+        for v in range(11):
             for ks in (1, 2, 3):
                 os.environ["DEMON_FORCE_PLAN"] = "10,%d,%d" % (v, ks)
                 got = gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
