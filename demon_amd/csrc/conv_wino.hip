@@ -772,7 +772,7 @@ bool wino1d_variant_ok(int kind, int v)
 {
     if (kind < 0 || v < 0 || v >= WINO1D_VARIANTS) return false;
     // accumulators: NUV x TN x 4 registers per lane; two K groups per step (variants 4..7) double the staging registers: kinds 0 / 1 only
-    if (wino1d_variant_kg(v) == 2 && (kind > 1 || (kind == 1 && kW1Shapes[v].tn > 3))) return false;   // (register budget)
+    if (wino1d_variant_kg(v) == 2 && (kind == 3 || (kind == 2 && kW1Shapes[v].tn > 2) || (kind == 1 && kW1Shapes[v].tn > 3))) return false;   // (register budget)
     if (wino1d_variant_kg(v) == 4 && kind != 0) return false;                                            // (LDS: 16 channels x NUV per step)
     return wino1d_nuv(kind) * kW1Shapes[v].tn * 4 <= 112 && wino1d_lds_bytes(kind, v) <= 160 * 1024;
 }
@@ -844,7 +844,7 @@ static void launch_w1m(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
 template <int KIND, int AXIS, int WM, int WN, int TN, int KG>
 static void launch_w1(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    if constexpr (Wino1D<KIND>::NUV * TN * 4 <= 112 && (KG == 1 || KIND == 0 || (KIND == 1 && KG == 2 && TN <= 3)) && !(KIND == 1 && AXIS == 1 && TN == 3)) {
+    if constexpr (Wino1D<KIND>::NUV * TN * 4 <= 112 && (KG == 1 || KIND == 0 || (KIND == 1 && KG == 2 && TN <= 3) || (KIND == 2 && KG == 2 && TN == 2)) && !(KIND == 1 && AXIS == 1 && TN == 3)) {
         if (a.Cin % (4 * KG)) launch_w1m<KIND, AXIS, WM, WN, TN, KG, true>(a, grid, lds, s);
         else launch_w1m<KIND, AXIS, WM, WN, TN, KG, false>(a, grid, lds, s);
     }
