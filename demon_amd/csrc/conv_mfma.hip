@@ -322,8 +322,16 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(ConvArgs a)
     if (p >= P) return;
     const int co = blockIdx.y, cls = blockIdx.z;
     const float *__restrict__ ws = a.ws + (((long)cls * a.ksplit) * a.Mpad + co) * P + p;
+    // four slices per round: a reduce launch is a chain of memory latencies (one per dependent load), not a stream; the order of the
+    // additions stays slice 0, 1, 2 ... (what the in-launch form and the tests expect)
+    const long zs = (long)a.Mpad * P;
     float v = 0.0f;
-    for (int z = 0; z < a.ksplit; ++z) v += ws[(long)z * a.Mpad * P];
+    int z = 0;
+    for (; z + 4 <= a.ksplit; z += 4) {
+        const float s0 = ws[z * zs], s1 = ws[(z + 1) * zs], s2 = ws[(z + 2) * zs], s3 = ws[(z + 3) * zs];
+        v = (((v + s0) + s1) + s2) + s3;
+    }
+    for (; z < a.ksplit; ++z) v += ws[z * zs];
     v += a.bias[co];
     if (a.act) v = v >= 0.0f ? v : 0.1f * v;
     const int x = (int)(p % a.Wp);
@@ -343,8 +351,15 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce4_kernel(ConvArgs a)
     if (p >= P) return;
     const int co = blockIdx.y;
     const float *__restrict__ ws = a.ws + (long)co * P + p;
+    const long zs = (long)a.Mpad * P;
     floatx4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int z = 0; z < a.ksplit; ++z) v += *reinterpret_cast<const floatx4 *>(ws + (long)z * a.Mpad * P);
+    int z = 0;
+    for (; z + 4 <= a.ksplit; z += 4) {   // (four loads in flight, additions in slice order)
+        const floatx4 s0 = *reinterpret_cast<const floatx4 *>(ws + z * zs), s1 = *reinterpret_cast<const floatx4 *>(ws + (z + 1) * zs);
+        const floatx4 s2 = *reinterpret_cast<const floatx4 *>(ws + (z + 2) * zs), s3 = *reinterpret_cast<const floatx4 *>(ws + (z + 3) * zs);
+        v = (((v + s0) + s1) + s2) + s3;
+    }
+    for (; z < a.ksplit; ++z) v += *reinterpret_cast<const floatx4 *>(ws + z * zs);
     const float b = a.bias[co];
     const int x = (int)(p % a.Wp);
     const long t = p / a.Wp;
