@@ -58,4 +58,8 @@ def median3x3_downsample(input):
 
 
 def depth_to_normals(depth, intrinsics, inverse_depth=False):
+    """lmbspecialops.depth_to_normals as v2/losses.py:336-337 calls it.  UNVERIFIED against lmbspecialops (its sources are not in the
+    reference tree): pixel centres at +0.5, the one-sided difference with the smaller magnitude, normals pointing towards the
+    camera and NaN on the one-pixel border are this implementation's reading of the op's documentation (oracle/demon_oracle.c
+    states the same); pinned only by an analytic plane test (tests/test_pins.py)."""
     return _ctx().depth_to_normals(depth, intrinsics, inverse_depth)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): bash tools/collect_profiles.sh <round tag, e.g. r03>
-# Writes everything under gpurun_out/<tag>_profiles/; copy the summaries into profiles/ afterwards (tools/finish_profiles.sh does).
+# Writes everything under gpurun_out/<tag>_profiles/; copy the summaries into profiles/ afterwards (tools/finish_profiles.py does).
 #   1. bench records of every workload (+ per-launch table of the headline config)
 #   2. rocprofv3 --kernel-trace --stats of the headline bench (graph replay)
 #   3. PMC passes of the headline bench, one counter group per run (FETCH_SIZE / WRITE_SIZE / MFMA busy), as MI355X_MICROARCH.md prescribes
