@@ -336,7 +336,7 @@ def main():
             result["roofline_worst"] = roofline_entry(worst_tag)
             fam_achieved = flops / (ms * 1e-3) / 1e12
             result["roofline_family"] = {
-                "kernel": "all conv / deconv / dense launches (wino_deconv, wino1d, conv_frag, conv_frag_chain, conv_stream, conv_stream_chain, conv_patch, deconv4, conv_pair, conv_thin, dense_stream, conv_mfma, conv_small kernels)",
+                "kernel": "all conv / deconv / dense launches (wino_deconv, wino1d, conv_frag, conv_frag_chain, conv_stream, conv_stream_chain, conv_patch, deconv4, conv_pair, conv_thin, conv_row, dense_stream, conv_mfma, conv_small kernels)",
                 "executed_frac": sum(r["flops"] * executed_share(r["kernel"].split("+")[0]) for r in conv) / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 "note": "`achieved` / `frac` price the ALGORITHMIC flops (2 * MAC of the direct convolutions, BASELINE.md section 2); the minimal-filtering kernels (conv_wino.hip) execute fewer multiply-adds for the same sums: `executed_frac` is the matrix-pipe share",
                 "bound": "mfma", "achieved": fam_achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -787,6 +787,30 @@ bool run_thin(const Layer *L, const ConvArgs &a, hipStream_t s)
     return true;
 }
 
+// 1 x 7 / 1 x 9 stride-2 convs with <= 32 channels on both sides, whole reduction out of LDS (conv_row.hip), plan kind 13; reads the
+// transformed weights of the 1-D minimal-filtering kernel (d_w1)
+bool row_applies(const Layer *L)
+{
+    return L->kind == Layer::CONV && !L->scale && L->d_w1 != nullptr && L->wino1d_cross() == 1 &&
+           conv_row_shape_ok(L->kh, L->kw, L->sh, L->sw, L->ph, L->pw, L->Cin, L->Mpad, L->in.W, L->out.W);
+}
+
+bool run_row(const Layer *L, const ConvArgs &a, hipStream_t s)
+{
+    refresh_stream_weights(L, s);
+    RowArgs r;
+    r.in = a.in; r.out = a.out; r.wu = L->d_w1; r.bias = a.bias;
+    r.N = a.N; r.Cin = L->Cin; r.Cin4 = L->Cin4(); r.H = a.H; r.W = a.W; r.in_n_stride = a.in_n_stride;
+    r.Cout = L->Cout; r.Ho = a.Ho; r.Wo = a.Wo; r.out_n_stride = a.out_n_stride; r.out_plane = a.out_plane;
+    r.pad = L->pw; r.act = a.act; r.tiles_y = r.tiles_x = 0;
+    static const int num_cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+    r.num_cus = num_cus;
+    if (!launch_conv_row(r, L->kw, s)) return false;
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_row<32x128,t%d>", L->kw);
+    g_last_kernel = g_kernel_tag;
+    return true;
+}
+
 void run_mfma(const ConvArgs &a_in, ConvPlan plan, int ncls, hipStream_t s)
 {
     ConvArgs a = a_in;
@@ -826,6 +850,8 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 }
             } else if (kind == 10) {
                 if (wino1d_applies(L) && run_wino1d(L, a, tile, clamp_split(ks % 1000), s)) return;
+            } else if (kind == 13) {
+                if (row_applies(L) && run_row(L, a, s)) return;
             } else if (kind == 12) {
                 if (thin_applies(L) && run_thin(L, a, s)) return;
             } else if (kind == 11) {
@@ -865,6 +891,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             if (t.kind == 8 && wino_applies(L) && run_wino(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 10 && wino1d_applies(L) && run_wino1d(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 12 && thin_applies(L) && run_thin(L, a, s)) return;
+            if (t.kind == 13 && row_applies(L) && run_row(L, a, s)) return;
             if (t.kind == 11 && dense_stream_applies(L) && run_dense_stream(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
@@ -886,6 +913,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
         if (wino1d_applies(L) && v < WINO1D_VARIANTS && run_wino1d(L, a, v, clamp_split(L->force_split), s)) return;
         if (dense_stream_applies(L) && v < DENSE_VARIANTS && run_dense_stream(L, a, v, clamp_split(L->force_split), s)) return;
         if (thin_applies(L) && v == 0 && run_thin(L, a, s)) return;
+        if (row_applies(L) && v == 100 && run_row(L, a, s)) return;   // (tile 500: the other variants of this layer are the 1-D kernel's)
     }
     if (L->force_tile >= 300 && L->force_tile < 400) {  // demon_bench_layer: fragment-tiled kernel variant force_tile - 300
         const int v = L->force_tile - 300;
@@ -995,6 +1023,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
         }
     }
     if (thin_applies(L)) cands.push_back({12, 0, 1});
+    if (row_applies(L)) cands.push_back({13, 0, 1});
     if (dense_stream_applies(L)) {
         const long blocks = (long)(L->Mpad / 128) * ((n + 31) / 32);
         for (int ks : {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 32, 36, 48, 64}) {
@@ -2304,8 +2333,9 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
     // 8 = minimal-filtering transposed conv, 10 = 1-D minimal filtering (conv_wino.hip); 9 = the removed F(2x2,3x3) kernel (docs/experiments)
     // 11 = weight-streaming dense layer (dense_stream.hip; tile 0 / 1 = default / non-temporal weight loads)
     // 12 = the blocks' first layer with the weights in registers (conv_thin.hip; tile 0); its pair then runs as two launches
-    if (kind < 0 || kind > 12 || kind == 2 || kind == 9 || tile < 0 ||
-        tile >= (kind == 12 ? 1 : kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
+    // 13 = 1 x 7 / 1 x 9 stride-2 conv with <= 32 channels, whole reduction out of LDS (conv_row.hip; tile 0)
+    if (kind < 0 || kind > 13 || kind == 2 || kind == 9 || tile < 0 ||
+        tile >= (kind >= 12 ? 1 : kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
@@ -2313,6 +2343,7 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             if (kind == 8 && !wino_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the minimal-filtering kernel applies to transposed convs only");
             if (kind == 10 && !wino1d_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "no 1-D minimal-filtering form for this layer");
+            if (kind == 13 && !row_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_row.hip applies to 1 x 7 / 1 x 9 stride-2 convs with at most 32 channels on both sides only");
             if (kind == 12 && !thin_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_thin.hip applies to the 9 x 1 stride-2 first layer (Cin <= 6, Cout <= 32) only");
             if (kind == 11 && !dense_stream_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the weight-streaming kernel applies to dense layers only");
             if (kind == 4 && (!L->stream_ok() || L->Mpad % stream_variant_bm(tile))) return fail(c, DEMON_ERR_INVALID, "the streaming kernel does not apply to this layer");
@@ -2723,7 +2754,7 @@ int demon_last_kernel(char *tag, int tag_cap)
 int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int cout, int kh, int kw, int sh, int sw,
                       int tile, int ksplit, int iters, float *avg_ms, double *flops)
 {
-    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || (tile >= 200 + STREAM_VARIANTS && tile < 300) || (tile >= 300 + FRAG_VARIANTS && tile < 400) || tile >= 400 + WINO1D_VARIANTS) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || (tile >= 200 + STREAM_VARIANTS && tile < 300) || (tile >= 300 + FRAG_VARIANTS && tile < 400) || (tile >= 400 + WINO1D_VARIANTS && tile != 500)) return fail(c, DEMON_ERR_INVALID, "bad argument");
     hipSetDevice(c->device);
     demon_ctx scratch;
     scratch.device = c->device;

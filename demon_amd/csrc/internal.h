@@ -376,6 +376,22 @@ struct ThinArgs {
 bool conv_thin_shape_ok(int kh, int kw, int sh, int sw, int ph, int pw, int Cin, int Mpad, int W, int Wo);
 void launch_conv_thin(ThinArgs a, hipStream_t stream);
 
+// ---- 1 x k stride-2 convs with <= 32 channels on both sides, whole reduction out of LDS (conv_row.hip) ---------------------------------
+struct RowArgs {
+    const float *in;
+    float *out;
+    const float *wu;     // transformed weights U[e][Cin4][32] (wino1d_repack_kernel)
+    const float *bias;
+    int N, Cin, Cin4, H, W;
+    long in_n_stride;
+    int Cout, Ho, Wo;
+    long out_n_stride, out_plane;
+    int pad, act, num_cus;
+    int tiles_y, tiles_x;   // (set by the launcher)
+};
+bool conv_row_shape_ok(int kh, int kw, int sh, int sw, int ph, int pw, int Cin, int Mpad, int W, int Wo);
+bool launch_conv_row(RowArgs a, int taps, hipStream_t stream);
+
 // ---- tiny heads (conv_small.hip): VALU direct conv for Cout <= 4, fused motion tail -------------------------------------
 struct SmallConvArgs {
     const float *in;

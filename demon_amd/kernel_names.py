@@ -63,6 +63,9 @@ def kernel_tag(name):
         wide = {(4, 1, 3, 4): 8, (2, 2, 3, 2): 9, (4, 2, 3, 4): 10}   # 48 / 96 tiles per workgroup
         v = wide[(wm, wn, tn, kg)] if (wm, wn, tn, kg) in wide else shapes.get((wm, wn, tn), -1) + 4 * (kg - 1)
         return "wino1d<t%d,v%d>" % (3 if kind == 0 else 3 + 2 * kind, v)
+    m = re.search(r"conv_row_kernel<(\d+), ", name)
+    if m:
+        return "conv_row<32x128,t%d>" % (3 + 2 * int(m.group(1)))
     m = re.search(r"conv_thin_kernel<(\d+)", name)
     if m:
         return "conv_thin<32x512,t%s>" % m.group(1)

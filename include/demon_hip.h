@@ -107,6 +107,7 @@ int demon_autotune(demon_ctx *ctx, int n);
  *   11 weight-streaming kernel for the dense layers (dense_stream.hip: dense5 of v2, motion_fc1; tile 0 / 1 = default /
  *      non-temporal weight loads, ksplit = K slices), 12 the blocks' first layer (9 x 1, stride 2, <= 6 input channels) with the weights
  *      in registers (conv_thin.hip; tile 0) -- on that layer it also means: the conv1 pair runs as two launches, not as conv_pair.hip's one,
+ *   13 1 x 7 / 1 x 9 stride-2 conv with at most 32 channels on both sides, whole reduction out of LDS (conv_row.hip; tile 0),
  *        3 small-Cout VALU kernel, 4 register-streaming kernel (conv_stream.hip), 5 fragment-tiled kernel (conv_frag.hip),
  *        6 / 7 on the k x 1 layer of a stride-1 pair: the pair runs as ONE chained launch of conv_frag / conv_stream variant `tile`;
  *   tile = tile / variant id of that kernel; ksplit = K slices (kinds 0 / 4 / 5: + 1000 = slices combined inside the launch
@@ -244,7 +245,7 @@ int demon_op_dense(demon_ctx *ctx, float *out, const float *in, const float *w_i
 /* ---- tuning / diagnostics ----------------------------------------------------------------------------
  * Times one contraction layer (kind 0 conv, 1 transposed conv k4 s2, 2 dense) on device-resident random
  * data with hip events; tile < 0 / ksplit <= 0 select the automatic plan (tile 0..7 im2col tiles, 100 + t patch tiles,
- * 200 + v streaming-kernel variants, 300 + v fragment-tiled variants, 400 + v minimal-filtering variants (transposed conv / k x 1, 1 x k, 3 x 3 conv) resp. 400 = the weight-streaming kernel on a dense layer).
+ * 200 + v streaming-kernel variants, 300 + v fragment-tiled variants, 400 + v minimal-filtering variants (transposed conv / k x 1, 1 x k, 3 x 3 conv) resp. 400 = the weight-streaming kernel on a dense layer / the first-layer kernel, 500 = conv_row.hip).
  * Not on the reference's path. */
 int demon_bench_layer(demon_ctx *ctx, int kind, int n, int cin, int h, int w, int cout, int kh, int kw, int sh,
                       int sw, int tile, int ksplit, int iters, float *avg_ms, double *flops);

@@ -97,6 +97,7 @@ def test_shipped_plans_are_well_formed():
     limits[6], limits[7] = limits[5], limits[4]
     limits[8] = int(re.search(r"WINO_VARIANTS\s*=\s*(\d+)", src).group(1))      # minimal-filtering transposed conv (conv_wino.hip)
     limits[10] = int(re.search(r"WINO1D_VARIANTS\s*=\s*(\d+)", src).group(1))   # 1-D minimal filtering; 9 is not a kernel
+    limits[13] = 1                                                               # 1 x 7 / 1 x 9 stride-2 conv out of LDS (conv_row.hip)
     limits[12] = 1                                                               # first layer, weights in registers (conv_thin.hip)
     limits[11] = 2                                                               # weight-streaming dense layer (dense_stream.hip)
     files = sorted(glob.glob(os.path.join(root, "tuned", "plan_*.json")))
@@ -131,6 +132,8 @@ def test_kernel_names_round_trip():
         "void demon::wino1d_kernel<1, 0, 2, 2, 3, 2, true>(demon::Wino1Args)": "wino1d<t5,v9>",
         "void demon::dense_stream_kernel<true, 0>(demon::DenseArgs)": "dense_stream<128x32,v1>",
         "void demon::conv_thin_kernel<9, 2, 14>(demon::ThinArgs)": "conv_thin<32x512,t9>",
+        "void demon::conv_row_kernel<3, true>(demon::RowArgs)": "conv_row<32x128,t9>",
+        "void demon::conv_row_kernel<2, false>(demon::RowArgs)": "conv_row<32x128,t7>",
     }
     for name, tag in cases.items():
         assert kernel_tag(name) == tag

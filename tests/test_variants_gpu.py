@@ -262,3 +262,32 @@ def test_first_layer_weights_in_registers(gpu_ctx, layer):
         np.testing.assert_array_equal(np.where(lin >= 0, lin, np.float32(0.1) * lin), got)
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+# (cin, cout, taps, H, W)
+ROW_LAYERS = [(32, 32, 9, 96, 256), (32, 32, 7, 48, 128), (24, 32, 9, 20, 136), (32, 24, 7, 7, 64), (30, 32, 9, 5, 72), (16, 16, 9, 6, 260)]
+
+
+@pytest.mark.parametrize("layer", ROW_LAYERS)
+def test_row_conv_out_of_lds(gpu_ctx, layer):
+    """conv_row.hip (plan kind 13): the 1 x 9 / 1 x 7 stride-(1,2) convs with <= 32 channels on both sides (conv1x of every block,
+    conv2x of the iterative nets; helpers.py:105-153) in the minimal-filtering form of wino1d_tables.h with the whole reduction out
+    of LDS.  Against PyTorch: image borders, partial row / column tiles, channel counts below the tile's and not a multiple of 4"""
+    cin, cout, taps, H, W = layer
+    rng = np.random.default_rng(37)
+    n = 3
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((1, taps, cin, cout)) / np.sqrt(taps * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("conv", x, w, b, (1, 2))
+    try:
+        os.environ["DEMON_FORCE_PLAN"] = "13,0,1"
+        got = gpu_ctx.conv2d(x, w, b, (1, 2), lrelu=True)
+        assert gpu_ctx.last_kernel().startswith("conv_row<"), gpu_ctx.last_kernel()
+        assert got.shape == want.shape
+        assert rel_l1(got, want) < 1e-5
+        np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (1, 2), lrelu=True))
+        lin = gpu_ctx.conv2d(x, w, b, (1, 2), lrelu=False)
+        np.testing.assert_array_equal(np.where(lin >= 0, lin, np.float32(0.1) * lin), got)
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)

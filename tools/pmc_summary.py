@@ -29,7 +29,7 @@ def load(d):
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
-            fam = "conv" if any(k in name for k in ("conv_mfma_kernel", "conv_patch_kernel", "deconv4_kernel", "conv_pair_kernel", "conv_stream_kernel", "conv_frag_kernel", "conv_frag_chain_kernel", "conv_stream_chain_kernel", "wino_deconv_kernel", "wino1d_kernel", "dense_stream_kernel", "conv_thin_kernel")) else name.split("(")[0].replace("demon::", "")
+            fam = "conv" if any(k in name for k in ("conv_mfma_kernel", "conv_patch_kernel", "deconv4_kernel", "conv_pair_kernel", "conv_stream_kernel", "conv_frag_kernel", "conv_frag_chain_kernel", "conv_stream_chain_kernel", "wino_deconv_kernel", "wino1d_kernel", "dense_stream_kernel", "conv_thin_kernel", "conv_row_kernel")) else name.split("(")[0].replace("demon::", "")
             agg[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg["kernel:" + kernel_tag(name)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
