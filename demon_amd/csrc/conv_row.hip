@@ -221,7 +221,13 @@ bool launch_conv_row(RowArgs a, int taps, hipStream_t stream)
     const int nuv = taps + 2;
     const size_t lds = sizeof(float) * ((size_t)(a.Cin4 / 4) * nuv * 128 + (size_t)a.Cin4 * ROW_R * ROW_PW);
     const int ntiles = a.N * a.tiles_y * a.tiles_x;
-    const dim3 grid((unsigned)(ntiles < 2 * a.num_cus ? ntiles : 2 * a.num_cus));   // persistent: two workgroups per CU walk the tiles
+    // a workgroup walks `tpw` tiles (stride = grid size) and retires: U is staged once per tpw tiles, and other streams' workgroups
+    // get a CU's LDS every few microseconds (fully persistent workgroups -- two per CU for the whole launch -- were 4 us faster alone
+    // and gained nothing in the pipeline: the side stream's kernels could not start beside them)
+    static const int tpw_env = getenv("DEMON_ROW_TPW") ? atoi(getenv("DEMON_ROW_TPW")) : 0;
+    const int tpw = tpw_env > 0 ? tpw_env : 3;
+    const int wgs = (ntiles + tpw - 1) / tpw;
+    const dim3 grid((unsigned)(wgs < 1 ? 1 : wgs));
     const bool caffe = a.pad == taps / 2;
     if (taps == 9) return caffe ? launch_row_t<3, true>(a, grid, lds, stream) : launch_row_t<3, false>(a, grid, lds, stream);
     return caffe ? launch_row_t<2, true>(a, grid, lds, stream) : launch_row_t<2, false>(a, grid, lds, stream);
