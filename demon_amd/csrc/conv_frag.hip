@@ -26,9 +26,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // KW > 1: KW groups of WM x WN waves share the output tile and split its K range (each with its own LDS buffers, all meeting at the
 // same barriers); their accumulators are summed through LDS in group order at the end -- split-K without partial sums in HBM and
 // without a reduce launch, for the layers whose tiles are too few to fill the chip.
-// INL: the instantiation that combines split-K slices inside the launch (kept apart: its extra live registers cost the ordinary
-// kernels of the 64-row wave tiles a wave of occupancy when the code sits behind a run-time branch)
-template <int WM, int WN, int TM, int TN, int KS, int KW, bool INL>
+template <int WM, int WN, int TM, int TN, int KS, int KW>
 __device__ __forceinline__ void frag_tile(const StreamArgs &s)
 {
     const ConvArgs &a = s.c;
@@ -261,25 +259,21 @@ __device__ __forceinline__ void frag_tile(const StreamArgs &s)
     // ---- epilogue (as conv_mfma.hip)
     const int mw = m0 + wm * TM * 32;
     const long pw = p0 + (long)wn * TN * 32;
-    if (a.ksplit > 1) {
-        if constexpr (INL) {  // combined inside this launch (internal.h)
-            if (!splitk_combine_in_launch<TM, TN>(acc, a.ws, a.tickets, a.ksplit, cls, zs, WM * WN, wave)) return;
-        } else {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
-            float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
+    if (a.ksplit > 1) {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
+        float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const long p = pw + j * 32 + l31;
-                if (p >= P) continue;
+        for (int j = 0; j < TN; ++j) {
+            const long p = pw + j * 32 + l31;
+            if (p >= P) continue;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = mw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        ws[(long)co * P + p] = acc[i][j][r];
-                    }
-            }
-            return;
+                for (int r = 0; r < 16; ++r) {
+                    const int co = mw + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    ws[(long)co * P + p] = acc[i][j][r];
+                }
         }
+        return;
     }
     const int pyc = cls >> 1, pxc = cls & 1;
     const long plane = a.out_plane;
@@ -352,10 +346,10 @@ __device__ __forceinline__ void frag_tile(const StreamArgs &s)
     }
 }
 
-template <int WM, int WN, int TM, int TN, int KS, int KW, bool INL>
+template <int WM, int WN, int TM, int TN, int KS, int KW>
 __global__ __launch_bounds__(64 * WM * WN * KW) void conv_frag_kernel(StreamArgs s)
 {
-    frag_tile<WM, WN, TM, TN, KS, KW, INL>(s);
+    frag_tile<WM, WN, TM, TN, KS, KW>(s);
 }
 
 // Two dependent layers in ONE launch: the k x 1 and the 1 x k conv of a stride-1 separable pair (helpers.py:105-153), when a
@@ -367,9 +361,9 @@ __global__ __launch_bounds__(64 * WM * WN * KW) void conv_frag_kernel(StreamArgs
 template <int WM, int WN, int TM, int TN, int KS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_frag_chain_kernel(StreamArgs s1, StreamArgs s2)
 {
-    frag_tile<WM, WN, TM, TN, KS, 1, false>(s1);
+    frag_tile<WM, WN, TM, TN, KS, 1>(s1);
     __syncthreads();   // workgroup-scope release / acquire around the barrier: the first layer's stores are complete and visible
-    frag_tile<WM, WN, TM, TN, KS, 1, false>(s2);
+    frag_tile<WM, WN, TM, TN, KS, 1>(s2);
 }
 
 
@@ -383,7 +377,7 @@ int frag_variant_bm(int v) { return 32 * kFragVariants[v].tm * kFragVariants[v].
 int frag_variant_bn(int v) { return 32 * kFragVariants[v].tn * kFragVariants[v].wn; }
 int frag_variant_kw(int v) { return kFragVariants[v].kw; }
 
-template <int WM, int WN, int TM, int TN, int KS, int KW, bool INL>
+template <int WM, int WN, int TM, int TN, int KS, int KW>
 static void launch_frag_instance(const StreamArgs &s, dim3 grid, hipStream_t stream)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -392,18 +386,11 @@ static void launch_frag_instance(const StreamArgs &s, dim3 grid, hipStream_t str
     constexpr size_t lds = tiles > red ? tiles : red;
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
     if (lds > 48 * 1024) {  // more dynamic LDS than the default limit: opt in once per instantiation
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_kernel<WM, WN, TM, TN, KS, KW, INL>),
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_kernel<WM, WN, TM, TN, KS, KW>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)once;
     }
-    hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN, KS, KW, INL>), grid, dim3(64 * WM * WN * KW), lds, stream, s);
-}
-
-template <int WM, int WN, int TM, int TN, int KS, int KW>
-static void launch_frag_variant(const StreamArgs &s, dim3 grid, hipStream_t stream)
-{
-    if (s.c.tickets) launch_frag_instance<WM, WN, TM, TN, KS, KW, true>(s, grid, stream);
-    else launch_frag_instance<WM, WN, TM, TN, KS, KW, false>(s, grid, stream);
+    hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN, KS, KW>), grid, dim3(64 * WM * WN * KW), lds, stream, s);
 }
 
 template <int WM, int WN, int TM, int TN, int KS>
@@ -425,7 +412,6 @@ bool launch_conv_frag_chain(const StreamArgs &s1_in, const StreamArgs &s2_in, in
     if (variant < 0 || variant >= FRAG_VARIANTS || kFragVariants[variant].kw != 1) return false;
     StreamArgs s1 = s1_in, s2 = s2_in;
     s1.c.ksplit = s2.c.ksplit = 1;
-    s1.c.tickets = s2.c.tickets = nullptr;
     const ConvArgs &a = s1.c, &b = s2.c;
     const int bm = frag_variant_bm(variant), bn = frag_variant_bn(variant);
     const bool same_grid = a.N == b.N && a.Hp == b.Hp && a.Wp == b.Wp && a.Mpad == b.Mpad;
@@ -454,7 +440,7 @@ bool launch_conv_frag_chain(const StreamArgs &s1_in, const StreamArgs &s2_in, in
     return true;
 }
 
-bool launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
+void launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
 {
     StreamArgs s = s_in;
     s.c.ksplit = ksplit;
@@ -462,36 +448,31 @@ bool launch_conv_frag(const StreamArgs &s_in, int variant, int ksplit, int nclas
     const long P = (long)a.N * a.Hp * a.Wp;
     const int bm = frag_variant_bm(variant), bn = frag_variant_bn(variant);
     dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)(a.Mpad / bm), (unsigned)(nclasses * ksplit));
-    const FragVariant &fv = kFragVariants[variant];
-    if (ksplit <= 1 || (long)grid.x * grid.y * nclasses * fv.wm * fv.wn > kSplitKTickets ||
-        splitk_slab_floats((long)grid.x * grid.y, fv.wm * fv.wn, fv.tm, fv.tn, nclasses, ksplit) > kSplitKWorkspaceFloats)
-        s.c.tickets = nullptr;
     switch (variant) {
-        case 0: launch_frag_variant<2, 2, 2, 1, 1, 1>(s, grid, stream); break;
-        case 1: launch_frag_variant<2, 2, 1, 1, 1, 1>(s, grid, stream); break;
-        case 2: launch_frag_variant<2, 2, 2, 2, 1, 1>(s, grid, stream); break;
-        case 3: launch_frag_variant<2, 2, 1, 2, 1, 1>(s, grid, stream); break;
-        case 4: launch_frag_variant<4, 1, 2, 1, 1, 1>(s, grid, stream); break;
-        case 5: launch_frag_variant<1, 4, 2, 1, 1, 1>(s, grid, stream); break;
-        case 6: launch_frag_variant<4, 1, 1, 1, 1, 1>(s, grid, stream); break;
-        case 7: launch_frag_variant<1, 4, 2, 2, 1, 1>(s, grid, stream); break;
-        case 8: launch_frag_variant<2, 2, 1, 1, 2, 1>(s, grid, stream); break;
-        case 9: launch_frag_variant<4, 1, 1, 1, 2, 1>(s, grid, stream); break;
-        case 10: launch_frag_variant<2, 2, 2, 1, 2, 1>(s, grid, stream); break;
-        case 11: launch_frag_variant<1, 4, 2, 1, 2, 1>(s, grid, stream); break;
-        case 12: launch_frag_variant<2, 2, 1, 2, 2, 1>(s, grid, stream); break;
-        case 13: launch_frag_variant<1, 4, 1, 1, 2, 1>(s, grid, stream); break;
-        case 14: launch_frag_variant<4, 1, 1, 1, 1, 2>(s, grid, stream); break;
-        case 15: launch_frag_variant<4, 1, 1, 1, 1, 4>(s, grid, stream); break;
-        case 16: launch_frag_variant<2, 2, 1, 1, 1, 2>(s, grid, stream); break;
-        case 17: launch_frag_variant<2, 2, 1, 1, 1, 4>(s, grid, stream); break;
-        case 18: launch_frag_variant<2, 2, 2, 1, 1, 2>(s, grid, stream); break;
-        case 19: launch_frag_variant<2, 2, 2, 1, 1, 4>(s, grid, stream); break;
-        case 20: launch_frag_variant<1, 4, 2, 1, 1, 2>(s, grid, stream); break;
-        default: launch_frag_variant<4, 1, 2, 1, 1, 2>(s, grid, stream); break;
+        case 0: launch_frag_instance<2, 2, 2, 1, 1, 1>(s, grid, stream); break;
+        case 1: launch_frag_instance<2, 2, 1, 1, 1, 1>(s, grid, stream); break;
+        case 2: launch_frag_instance<2, 2, 2, 2, 1, 1>(s, grid, stream); break;
+        case 3: launch_frag_instance<2, 2, 1, 2, 1, 1>(s, grid, stream); break;
+        case 4: launch_frag_instance<4, 1, 2, 1, 1, 1>(s, grid, stream); break;
+        case 5: launch_frag_instance<1, 4, 2, 1, 1, 1>(s, grid, stream); break;
+        case 6: launch_frag_instance<4, 1, 1, 1, 1, 1>(s, grid, stream); break;
+        case 7: launch_frag_instance<1, 4, 2, 2, 1, 1>(s, grid, stream); break;
+        case 8: launch_frag_instance<2, 2, 1, 1, 2, 1>(s, grid, stream); break;
+        case 9: launch_frag_instance<4, 1, 1, 1, 2, 1>(s, grid, stream); break;
+        case 10: launch_frag_instance<2, 2, 2, 1, 2, 1>(s, grid, stream); break;
+        case 11: launch_frag_instance<1, 4, 2, 1, 2, 1>(s, grid, stream); break;
+        case 12: launch_frag_instance<2, 2, 1, 2, 2, 1>(s, grid, stream); break;
+        case 13: launch_frag_instance<1, 4, 1, 1, 2, 1>(s, grid, stream); break;
+        case 14: launch_frag_instance<4, 1, 1, 1, 1, 2>(s, grid, stream); break;
+        case 15: launch_frag_instance<4, 1, 1, 1, 1, 4>(s, grid, stream); break;
+        case 16: launch_frag_instance<2, 2, 1, 1, 1, 2>(s, grid, stream); break;
+        case 17: launch_frag_instance<2, 2, 1, 1, 1, 4>(s, grid, stream); break;
+        case 18: launch_frag_instance<2, 2, 2, 1, 1, 2>(s, grid, stream); break;
+        case 19: launch_frag_instance<2, 2, 2, 1, 1, 4>(s, grid, stream); break;
+        case 20: launch_frag_instance<1, 4, 2, 1, 1, 2>(s, grid, stream); break;
+        default: launch_frag_instance<4, 1, 2, 1, 1, 2>(s, grid, stream); break;
     }
-    if (ksplit > 1 && !s.c.tickets) launch_splitk_reduce(s.c, nclasses, stream);
-    return s.c.tickets != nullptr;
+    if (ksplit > 1) launch_splitk_reduce(s.c, nclasses, stream);
 }
 
 }  // namespace demon

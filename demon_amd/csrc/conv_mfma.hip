@@ -29,7 +29,7 @@ namespace demon {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WM, int WN, bool INL>  // INL: split-K slices combined inside the launch (see conv_frag.hip)
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
 {
     constexpr int BK = 16;
@@ -218,25 +218,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a)
     if (nsteps > 0) kstep(s & 1, 0, kentA, kentB, std::false_type{});
     tl.mark(2);
 
-    if (a.ksplit > 1) {
-        if constexpr (INL) {  // combined inside this launch (internal.h)
-            if (!splitk_combine_in_launch<TM, TN>(acc, a.ws, a.tickets, a.ksplit, cls, zs, WM * WN, tid >> 6)) return;
-        } else {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
-            float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
+    if (a.ksplit > 1) {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
+        float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const long p = p0 + (wn * TN + j) * 32 + l31;
-                if (p >= P) continue;
+        for (int j = 0; j < TN; ++j) {
+            const long p = p0 + (wn * TN + j) * 32 + l31;
+            if (p >= P) continue;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        ws[(long)co * P + p] = acc[i][j][r];
-                    }
-            }
-            return;
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    ws[(long)co * P + p] = acc[i][j][r];
+                }
         }
+        return;
     }
     // ---- epilogue: bias, leaky relu, optional per-sample scale of channel 0, coalesced NCHW store
     const int pyc = cls >> 1, pxc = cls & 1;  // cls = 0 for plain convs
@@ -416,21 +412,16 @@ int conv_tile_bn(int tile) { return kTiles[tile].bn; }
 template <int BM, int BN, int WM, int WN>
 static void launch_tile(const ConvArgs &a, dim3 grid, hipStream_t stream)
 {
-    if (a.tickets) hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, true>), grid, dim3(64 * WM * WN), 0, stream, a);
-    else hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, false>), grid, dim3(64 * WM * WN), 0, stream, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), 0, stream, a);
 }
 
-bool launch_conv_mfma(const ConvArgs &a_in, ConvPlan plan, int nclasses, hipStream_t stream)
+void launch_conv_mfma(const ConvArgs &a_in, ConvPlan plan, int nclasses, hipStream_t stream)
 {
     ConvArgs a = a_in;
     a.ksplit = plan.ksplit;
     const long P = (long)a.N * a.Hp * a.Wp;
     const TileInfo ti = kTiles[plan.tile];
     dim3 grid((unsigned)((P + ti.bn - 1) / ti.bn), (unsigned)(a.Mpad / ti.bm), (unsigned)(nclasses * plan.ksplit));
-    const int tmn = ti.bm * ti.bn / 1024 / (ti.threads / 64);  // accumulator blocks per wave
-    if (plan.ksplit <= 1 || (long)grid.x * grid.y * nclasses * (ti.threads / 64) > kSplitKTickets ||
-        splitk_slab_floats((long)grid.x * grid.y, ti.threads / 64, tmn, 1, nclasses, plan.ksplit) > kSplitKWorkspaceFloats)
-        a.tickets = nullptr;
     switch (plan.tile) {
         case TILE_128x128: launch_tile<128, 128, 2, 2>(a, grid, stream); break;
         case TILE_64x128:  launch_tile<64, 128, 2, 2>(a, grid, stream); break;
@@ -441,8 +432,7 @@ bool launch_conv_mfma(const ConvArgs &a_in, ConvPlan plan, int nclasses, hipStre
         case TILE_64x32:   launch_tile<64, 32, 2, 1>(a, grid, stream); break;
         default:           launch_tile<32, 32, 1, 1>(a, grid, stream); break;
     }
-    if (plan.ksplit > 1 && !a.tickets) launch_splitk_reduce(a, nclasses, stream);
-    return a.tickets != nullptr;
+    if (plan.ksplit > 1) launch_splitk_reduce(a, nclasses, stream);
 }
 
 thread_local hipEvent_t g_reduce_mark = nullptr;

@@ -205,11 +205,8 @@ bool conv_row_shape_ok(int kh, int kw, int sh, int sw, int ph, int pw, int Cin, 
 template <int KIND, bool CAFFE>
 static bool launch_row_t(const RowArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_row_kernel<KIND, CAFFE>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return false;
-        configured = true;
-    }
+    static PerDeviceOnce once;
+    if (!once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_row_kernel<KIND, CAFFE>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess; })) return false;
     hipLaunchKernelGGL((conv_row_kernel<KIND, CAFFE>), grid, dim3(ROW_NT), lds, s, a);
     return true;
 }

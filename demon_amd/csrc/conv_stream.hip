@@ -67,8 +67,7 @@ struct StreamSet {
 // KW > 1 (small batches: few output tiles, long K): KW groups of NW waves share the tile and split its K range between them;
 // their partial accumulators are summed through LDS at the end, in wave order -- split-K without partial sums in HBM and
 // without a reduce launch.
-// INL: the instantiation that combines split-K slices inside the launch (see conv_frag.hip)
-template <int NW, int TM, int TN, int KW, bool INL>
+template <int NW, int TM, int TN, int KW>
 __device__ __forceinline__ void stream_tile(const StreamArgs &s)
 {
     const ConvArgs &a = s.c;
@@ -254,25 +253,21 @@ __device__ __forceinline__ void stream_tile(const StreamArgs &s)
     }
 
     // ---- epilogue (as conv_mfma.hip)
-    if (a.ksplit > 1) {
-        if constexpr (INL) {  // combined inside this launch (internal.h)
-            if (!splitk_combine_in_launch<TM, TN>(acc, a.ws, a.tickets, a.ksplit, cls, zs, NW, wave)) return;
-        } else {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
-            float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
+    if (a.ksplit > 1) {  // raw partial sums to the workspace [cls][slice][Mpad][P]; conv_splitk_reduce finishes
+        float *__restrict__ ws = a.ws + ((long)blockIdx.z * a.Mpad) * P;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const long p = p0 + j * 32 + l31;
-                if (p >= P) continue;
+        for (int j = 0; j < TN; ++j) {
+            const long p = p0 + j * 32 + l31;
+            if (p >= P) continue;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                        ws[(long)co * P + p] = acc[i][j][r];
-                    }
-            }
-            return;
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    ws[(long)co * P + p] = acc[i][j][r];
+                }
         }
+        return;
     }
     const int pyc = cls >> 1, pxc = cls & 1;
     const long plane = a.out_plane;
@@ -346,10 +341,10 @@ __device__ __forceinline__ void stream_tile(const StreamArgs &s)
     }
 }
 
-template <int NW, int TM, int TN, int KW, bool INL>
+template <int NW, int TM, int TN, int KW>
 __global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
 {
-    stream_tile<NW, TM, TN, KW, INL>(s);
+    stream_tile<NW, TM, TN, KW>(s);
 }
 
 // the k x 1 and the 1 x k conv of a stride-1 separable pair in one launch (see conv_frag_chain_kernel, conv_frag.hip): the NW waves
@@ -357,9 +352,9 @@ __global__ __launch_bounds__(64 * NW * KW) void conv_stream_kernel(StreamArgs s)
 template <int NW, int TM, int TN>
 __global__ __launch_bounds__(64 * NW) void conv_stream_chain_kernel(StreamArgs s1, StreamArgs s2)
 {
-    stream_tile<NW, TM, TN, 1, false>(s1);
+    stream_tile<NW, TM, TN, 1>(s1);
     __syncthreads();
-    stream_tile<NW, TM, TN, 1, false>(s2);
+    stream_tile<NW, TM, TN, 1>(s2);
 }
 
 
@@ -378,8 +373,7 @@ template <int NW, int TM, int TN, int KW>
 static void launch_stream_variant(const StreamArgs &s, dim3 grid, hipStream_t stream)
 {
     const size_t lds = KW > 1 ? sizeof(float) * KW * NW * TM * TN * 16 * 64 : 0;
-    if (s.c.tickets) hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW, true>), grid, dim3(64 * NW * KW), lds, stream, s);
-    else hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW, false>), grid, dim3(64 * NW * KW), lds, stream, s);
+    hipLaunchKernelGGL((conv_stream_kernel<NW, TM, TN, KW>), grid, dim3(64 * NW * KW), lds, stream, s);
 }
 
 bool launch_conv_stream_chain(const StreamArgs &s1_in, const StreamArgs &s2_in, int variant, hipStream_t stream)
@@ -387,7 +381,6 @@ bool launch_conv_stream_chain(const StreamArgs &s1_in, const StreamArgs &s2_in, 
     if (variant < 0 || variant >= STREAM_VARIANTS || kStreamVariants[variant].kw != 1) return false;
     StreamArgs s1 = s1_in, s2 = s2_in;
     s1.c.ksplit = s2.c.ksplit = 1;
-    s1.c.tickets = s2.c.tickets = nullptr;
     const ConvArgs &a = s1.c, &b = s2.c;
     const int bm = stream_variant_bm(variant), bn = stream_variant_bn(variant);
     const bool same_grid = a.N == b.N && a.Hp == b.Hp && a.Wp == b.Wp && a.Mpad == b.Mpad;
@@ -411,7 +404,7 @@ bool launch_conv_stream_chain(const StreamArgs &s1_in, const StreamArgs &s2_in, 
     return true;
 }
 
-bool launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
+void launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int nclasses, hipStream_t stream)
 {
     StreamArgs s = s_in;
     s.c.ksplit = ksplit;
@@ -419,10 +412,6 @@ bool launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int ncl
     const long P = (long)a.N * a.Hp * a.Wp;
     const int bm = stream_variant_bm(variant), bn = stream_variant_bn(variant);
     dim3 grid((unsigned)((P + bn - 1) / bn), (unsigned)(a.Mpad / bm), (unsigned)(nclasses * ksplit));
-    const StreamVariant &sv = kStreamVariants[variant];
-    if (ksplit <= 1 || (long)grid.x * grid.y * nclasses * sv.nw > kSplitKTickets ||
-        splitk_slab_floats((long)grid.x * grid.y, sv.nw, sv.tm, sv.tn, nclasses, ksplit) > kSplitKWorkspaceFloats)
-        s.c.tickets = nullptr;
     switch (variant) {
         case 0: launch_stream_variant<4, 1, 1, 1>(s, grid, stream); break;
         case 1: launch_stream_variant<4, 1, 2, 1>(s, grid, stream); break;
@@ -443,8 +432,7 @@ bool launch_conv_stream(const StreamArgs &s_in, int variant, int ksplit, int ncl
         case 16: launch_stream_variant<1, 2, 2, 8>(s, grid, stream); break;
         default: launch_stream_variant<2, 1, 1, 4>(s, grid, stream); break;
     }
-    if (ksplit > 1 && !s.c.tickets) launch_splitk_reduce(s.c, nclasses, stream);
-    return s.c.tickets != nullptr;
+    if (ksplit > 1) launch_splitk_reduce(s.c, nclasses, stream);
 }
 
 }  // namespace demon

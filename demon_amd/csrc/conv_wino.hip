@@ -831,59 +831,57 @@ void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin
 }
 
 template <int KIND, int AXIS, int WM, int WN, int TN, int KG, bool MASK>
-static void launch_w1m(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
+static bool launch_w1m(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&wino1d_kernel<KIND, AXIS, WM, WN, TN, KG, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        configured = true;
-    }
+    static PerDeviceOnce once;
+    if (!once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&wino1d_kernel<KIND, AXIS, WM, WN, TN, KG, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; })) return false;
     hipLaunchKernelGGL((wino1d_kernel<KIND, AXIS, WM, WN, TN, KG, MASK>), grid, dim3(64 * WM * WN), lds, s, a);
+    return true;
 }
 
 template <int KIND, int AXIS, int WM, int WN, int TN, int KG>
-static void launch_w1(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
+static bool launch_w1(const Wino1Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
     if constexpr (Wino1D<KIND>::NUV * TN * 4 <= 112 && (KG == 1 || KIND == 0 || (KIND == 1 && KG == 2 && TN <= 3) || (KIND == 2 && KG == 2 && TN == 2)) && !(KIND == 1 && AXIS == 1 && TN == 3)) {
-        if (a.Cin % (4 * KG)) launch_w1m<KIND, AXIS, WM, WN, TN, KG, true>(a, grid, lds, s);
-        else launch_w1m<KIND, AXIS, WM, WN, TN, KG, false>(a, grid, lds, s);
+        if (a.Cin % (4 * KG)) return launch_w1m<KIND, AXIS, WM, WN, TN, KG, true>(a, grid, lds, s);
+        return launch_w1m<KIND, AXIS, WM, WN, TN, KG, false>(a, grid, lds, s);
     }
+    return false;   // (no kernel of this shape for this filter: wino1d_variant_ok / wino1d_plan_geometry reject it first)
 }
 
 template <int KIND, int AXIS>
-static void launch_w1_variant(const Wino1Args &a, int variant, dim3 grid, size_t lds, hipStream_t s)
+static bool launch_w1_variant(const Wino1Args &a, int variant, dim3 grid, size_t lds, hipStream_t s)
 {
     switch (variant) {
-        case 0: launch_w1<KIND, AXIS, 2, 2, 2, 1>(a, grid, lds, s); break;
-        case 1: launch_w1<KIND, AXIS, 4, 1, 4, 1>(a, grid, lds, s); break;
-        case 2: launch_w1<KIND, AXIS, 2, 2, 4, 1>(a, grid, lds, s); break;
-        case 3: launch_w1<KIND, AXIS, 4, 2, 4, 1>(a, grid, lds, s); break;
-        case 4: launch_w1<KIND, AXIS, 2, 2, 2, 2>(a, grid, lds, s); break;
-        case 5: launch_w1<KIND, AXIS, 4, 1, 4, 2>(a, grid, lds, s); break;
-        case 6: launch_w1<KIND, AXIS, 2, 2, 4, 2>(a, grid, lds, s); break;
-        case 7: launch_w1<KIND, AXIS, 4, 2, 4, 2>(a, grid, lds, s); break;
-        case 8: launch_w1<KIND, AXIS, 4, 1, 3, 4>(a, grid, lds, s); break;
-        case 9: launch_w1<KIND, AXIS, 2, 2, 3, 2>(a, grid, lds, s); break;
-        default: launch_w1<KIND, AXIS, 4, 2, 3, 4>(a, grid, lds, s); break;
+        case 0: return launch_w1<KIND, AXIS, 2, 2, 2, 1>(a, grid, lds, s);
+        case 1: return launch_w1<KIND, AXIS, 4, 1, 4, 1>(a, grid, lds, s);
+        case 2: return launch_w1<KIND, AXIS, 2, 2, 4, 1>(a, grid, lds, s);
+        case 3: return launch_w1<KIND, AXIS, 4, 2, 4, 1>(a, grid, lds, s);
+        case 4: return launch_w1<KIND, AXIS, 2, 2, 2, 2>(a, grid, lds, s);
+        case 5: return launch_w1<KIND, AXIS, 4, 1, 4, 2>(a, grid, lds, s);
+        case 6: return launch_w1<KIND, AXIS, 2, 2, 4, 2>(a, grid, lds, s);
+        case 7: return launch_w1<KIND, AXIS, 4, 2, 4, 2>(a, grid, lds, s);
+        case 8: return launch_w1<KIND, AXIS, 4, 1, 3, 4>(a, grid, lds, s);
+        case 9: return launch_w1<KIND, AXIS, 2, 2, 3, 2>(a, grid, lds, s);
+        default: return launch_w1<KIND, AXIS, 4, 2, 3, 4>(a, grid, lds, s);
     }
 }
 
-void launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream)
+bool launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream)
 {
     const int groups = (a.N + a.G - 1) / a.G;
     dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / wino1d_variant_bm(variant)), (unsigned)a.ksplit);
     const size_t lds = wino1d_lds_bytes(kind, variant);
 #define W1_KIND(KK)                                                              \
     case KK:                                                                     \
-        if (axis == 0) launch_w1_variant<KK, 0>(a, variant, grid, lds, stream);  \
-        else launch_w1_variant<KK, 1>(a, variant, grid, lds, stream);            \
-        break;
+        return axis == 0 ? launch_w1_variant<KK, 0>(a, variant, grid, lds, stream)  \
+                         : launch_w1_variant<KK, 1>(a, variant, grid, lds, stream);
     switch (kind) {
         W1_KIND(0)
         W1_KIND(1)
         W1_KIND(2)
         W1_KIND(3)
-        default: break;
+        default: return false;
     }
 #undef W1_KIND
 }

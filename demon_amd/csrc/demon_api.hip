@@ -34,8 +34,8 @@ thread_local std::string g_create_error;
 unsigned long long *g_timeline_dev = nullptr;  // diagnostic build (demon_debug_timeline): where the kernels write their records
 thread_local const char *g_last_kernel = nullptr;
 thread_local char g_kernel_tag[48];
-// suffix of a kernel tag: "+splitk" = a conv_splitk_reduce launch follows, "+fixup" = K slices combined inside the launch
-const char *split_suffix(int ksplit, bool in_launch) { return ksplit > 1 ? (in_launch ? "+fixup" : "+splitk") : ""; }
+// suffix of a kernel tag: "+splitk" = a conv_splitk_reduce launch follows
+const char *split_suffix(int ksplit) { return ksplit > 1 ? "+splitk" : ""; }
 void set_kernel_tag(const char *family, int bm, int bn, int taps, bool splitk)
 {
     // e.g. "conv_mfma<128x32>+splitk" (rocprofv3: conv_mfma_kernel<128, 32, ...>), "conv_patch<64x128,t5>", "deconv4<32x128>"
@@ -160,7 +160,6 @@ struct demon_ctx {
     int opt_side_branches = 1;
     int opt_fused_pairs = 1;  // conv_pair.hip for the pairs conv_pair_applies() selects
     int opt_fused_inputs = 1;  // one launch for the extra-input assembly of the iterative blocks / the refinement input
-    int opt_tune_fixup = 0;    // demon_autotune also proposes "split-K combined inside the launch" (ksplit + 1000) candidates
     // all packed kernels and biases of the networks live in ONE device slab (alloc_weight_slab), so that
     // demon_broadcast_weights is a single RCCL broadcast of device-resident, already packed data
     float *w_slab = nullptr;
@@ -196,8 +195,7 @@ float *dev_alloc(demon_ctx *c, size_t bytes)
     return (float *)p;
 }
 
-// split-K workspace: kSplitKWorkspaceFloats of partial sums followed by kSplitKTickets arrival counters (zero whenever no
-// launch is in flight: the last arriver of a tile puts its counter back, internal.h)
+// split-K workspace: kSplitKWorkspaceFloats of partial sums [cls][slice][Mpad][P], finished by conv_splitk_reduce
 float *alloc_splitk_workspace(demon_ctx *c);
 
 // named activation buffer, sized for max_batch; same name -> same memory (the five sub-nets run one
@@ -293,7 +291,7 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
         }
     }
     if (L->wino1d_kind_of() >= 0 && !getenv("DEMON_NO_WINO")) {
-        const size_t nu = ((size_t)L->wino1d_cross() * wino1d_nuv(L->wino1d_kind_of()) * L->Cin4() + 8) * L->Mpad;   // + 8 rows: the two-K-group variants read (and multiply by zeros) up to 4 rows past the end
+        const size_t nu = ((size_t)L->wino1d_cross() * wino1d_nuv(L->wino1d_kind_of()) * L->Cin4() + 16) * L->Mpad;   // + 16 rows: a K-step of KG groups reads 4 KG - 4 rows past Cin4 at most (KG <= 4), times zero inputs
         L->d_w1 = dev_alloc(c, sizeof(float) * nu);
         if (!L->d_w1 || hipMemset(L->d_w1, 0, sizeof(float) * nu) != hipSuccess) return false;
         L->w1_dirty = true;
@@ -373,9 +371,7 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
 
 float *alloc_splitk_workspace(demon_ctx *c)
 {
-    float *ws = dev_alloc(c, sizeof(float) * kSplitKWorkspaceFloats + sizeof(unsigned) * kSplitKTickets);
-    if (ws && hipMemset(ws + kSplitKWorkspaceFloats, 0, sizeof(unsigned) * kSplitKTickets) != hipSuccess) return nullptr;
-    return ws;
+    return dev_alloc(c, sizeof(float) * kSplitKWorkspaceFloats);
 }
 
 void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
@@ -401,7 +397,6 @@ void fill_conv_args(const Layer *L, int n, float *ws, ConvArgs &a)
     a.act = L->act;
     a.cls_w_stride = (long)L->Krows * L->Mpad;
     a.ksplit = 1;
-    a.tickets = nullptr;
     a.tl = g_timeline_dev;
     static const int xcd_order = getenv("DEMON_XCD_ORDER") ? atoi(getenv("DEMON_XCD_ORDER")) : 1;
     a.xcd = xcd_order;
@@ -608,6 +603,10 @@ void refresh_stream_weights(const Layer *L, hipStream_t s)
         launch_wino1d_repack(L->d_w1, L->d_wp, L->wino1d_kind_of(), L->Cin, L->Cin4(), L->Mpad, L->wino1d_cross(), s);
         L->w1_dirty = false;
     }
+    if (L->d_wd && L->wd_dirty) {   // re-blocked weights of the weight-streaming dense kernel (dense_stream.hip)
+        launch_dense_repack(L->d_wd, L->d_wp, L->Cin, L->Mpad, s);
+        L->wd_dirty = false;
+    }
     if (!L->d_wf || !L->wf_dirty) return;
     launch_stream_repack(L->d_wf, L->d_wp, L->ncls, L->K, L->Mpad, (long)L->Krows * L->Mpad, s);
     L->wf_dirty = false;
@@ -646,35 +645,23 @@ int fill_stream_args(const Layer *L, const ConvArgs &a, int ksplit, StreamArgs &
     return ksplit;
 }
 
-// Plans of the kinds 0 / 4 / 5 store "combine the K slices inside the launch" (tickets, internal.h) as ksplit + 1000.
-unsigned *split_tickets(const ConvArgs &a, int &ksplit)
-{
-    const bool in_launch = ksplit >= 1000;
-    ksplit %= 1000;
-    return in_launch && a.ws ? reinterpret_cast<unsigned *>(a.ws + kSplitKWorkspaceFloats) : nullptr;
-}
-
 void run_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
 {
     StreamArgs sa;
-    unsigned *tickets = split_tickets(a, ksplit);
     ksplit = fill_stream_args(L, a, ksplit, sa, s);
-    sa.c.tickets = ksplit > 1 ? tickets : nullptr;
-    const bool in_launch = launch_conv_stream(sa, variant, ksplit, L->ncls, s);
+    launch_conv_stream(sa, variant, ksplit, L->ncls, s);
     // e.g. "conv_stream<256x32,w4k1>": tile, waves along Cout x K-splitting wave groups (rocprofv3: conv_stream_kernel<NW, TM, TN, KW>)
     snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_stream<%dx%d,w%dk%d>%s", stream_variant_bm(variant), stream_variant_bn(variant),
-             stream_variant_waves(variant) / stream_variant_kw(variant), stream_variant_kw(variant), split_suffix(ksplit, in_launch));
+             stream_variant_waves(variant) / stream_variant_kw(variant), stream_variant_kw(variant), split_suffix(ksplit));
     g_last_kernel = g_kernel_tag;
 }
 
 void run_frag(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
 {
     StreamArgs sa;
-    unsigned *tickets = split_tickets(a, ksplit);
     ksplit = fill_stream_args(L, a, ksplit, sa, s);
-    sa.c.tickets = ksplit > 1 ? tickets : nullptr;
-    const bool in_launch = launch_conv_frag(sa, variant, ksplit, L->ncls, s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_frag<%dx%d,v%d>%s", frag_variant_bm(variant), frag_variant_bn(variant), variant, split_suffix(ksplit, in_launch));
+    launch_conv_frag(sa, variant, ksplit, L->ncls, s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_frag<%dx%d,v%d>%s", frag_variant_bm(variant), frag_variant_bn(variant), variant, split_suffix(ksplit));
     g_last_kernel = g_kernel_tag;
 }
 
@@ -695,7 +682,7 @@ bool run_wino(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStr
     if (ksplit > w.nsteps_total) ksplit = w.nsteps_total;
     w.ksplit = ksplit;
     launch_wino_deconv(w, variant, s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino_deconv<16x%d>%s", 16 * wino_variant_tn(variant), split_suffix(ksplit, false));
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino_deconv<16x%d>%s", 16 * wino_variant_tn(variant), split_suffix(ksplit));
     g_last_kernel = g_kernel_tag;
     if (ksplit > 1) {
         ConvArgs r = a;
@@ -732,8 +719,8 @@ bool run_wino1d(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipS
     if (ksplit < 1) ksplit = 1;
     if (ksplit > w.nsteps_total) ksplit = w.nsteps_total;
     w.ksplit = ksplit;
-    launch_wino1d(w, L->wino1d_kind_of(), variant, L->wino1d_axis(), s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino1d<t%d%s,v%d>%s", L->wino1d_axis() == 0 ? L->kh : L->kw, L->wino1d_cross() > 1 ? "x3" : "", variant, split_suffix(ksplit, false));
+    if (!launch_wino1d(w, L->wino1d_kind_of(), variant, L->wino1d_axis(), s)) return false;
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino1d<t%d%s,v%d>%s", L->wino1d_axis() == 0 ? L->kh : L->kw, L->wino1d_cross() > 1 ? "x3" : "", variant, split_suffix(ksplit));
     g_last_kernel = g_kernel_tag;
     if (ksplit > 1) {
         ConvArgs r = a;
@@ -749,10 +736,7 @@ bool dense_stream_applies(const Layer *L) { return L->d_wd != nullptr; }
 bool run_dense_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStream_t s)
 {
     if (variant < 0 || variant >= DENSE_VARIANTS) return false;
-    if (L->wd_dirty) {
-        launch_dense_repack(L->d_wd, L->d_wp, L->Cin, L->Mpad, s);
-        L->wd_dirty = false;
-    }
+    refresh_stream_weights(L, s);   // (a no-op for network layers: prepare_stream_weights ran before any capture)
     if (ksplit < 1) ksplit = 1;
     while (ksplit > 1 && !dense_stream_geometry_ok(L->Cin, L->Mpad, ksplit)) --ksplit;
     if (!dense_stream_geometry_ok(L->Cin, L->Mpad, ksplit)) return false;
@@ -762,7 +746,7 @@ bool run_dense_stream(const Layer *L, const ConvArgs &a, int variant, int ksplit
     d.x_n_stride = a.in_n_stride; d.out_n_stride = a.out_n_stride;
     d.act = a.act; d.ksplit = ksplit;
     launch_dense_stream(d, variant, s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "dense_stream<128x32,v%d>%s", variant, split_suffix(ksplit, false));
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "dense_stream<128x32,v%d>%s", variant, split_suffix(ksplit));
     g_last_kernel = g_kernel_tag;
     return true;
 }
@@ -803,8 +787,6 @@ bool run_row(const Layer *L, const ConvArgs &a, hipStream_t s)
     r.N = a.N; r.Cin = L->Cin; r.Cin4 = L->Cin4(); r.H = a.H; r.W = a.W; r.in_n_stride = a.in_n_stride;
     r.Cout = L->Cout; r.Ho = a.Ho; r.Wo = a.Wo; r.out_n_stride = a.out_n_stride; r.out_plane = a.out_plane;
     r.pad = L->pw; r.act = a.act; r.tiles_y = r.tiles_x = 0;
-    static const int num_cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
-    r.num_cus = num_cus;
     if (!launch_conv_row(r, L->kw, s)) return false;
     snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_row<32x128,t%d>", L->kw);
     g_last_kernel = g_kernel_tag;
@@ -813,11 +795,8 @@ bool run_row(const Layer *L, const ConvArgs &a, hipStream_t s)
 
 void run_mfma(const ConvArgs &a_in, ConvPlan plan, int ncls, hipStream_t s)
 {
-    ConvArgs a = a_in;
-    a.tickets = split_tickets(a, plan.ksplit);
-    if (plan.ksplit <= 1) a.tickets = nullptr;
-    const bool in_launch = launch_conv_mfma(a, plan, ncls, s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_mfma<%dx%d>%s", conv_tile_bm(plan.tile), conv_tile_bn(plan.tile), split_suffix(plan.ksplit, in_launch));
+    launch_conv_mfma(a_in, plan, ncls, s);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "conv_mfma<%dx%d>%s", conv_tile_bm(plan.tile), conv_tile_bn(plan.tile), split_suffix(plan.ksplit));
     g_last_kernel = g_kernel_tag;
 }
 
@@ -827,10 +806,9 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
     fill_conv_args(L, n, ws, a);
     const long P = (long)n * a.Hp * a.Wp;
     auto clamp_split = [&](int k) {
-        const int in_launch = k >= 1000 ? 1000 : 0;  // see split_tickets
         k %= 1000;
         while (k > 1 && (!ws || (long)L->ncls * k * L->Mpad * P > kSplitKWorkspaceFloats)) --k;
-        return k > 1 ? k + in_launch : k;
+        return k;
     };
     // test hook: DEMON_FORCE_PLAN="kind,tile,ksplit" forces one kernel variant for every layer it applies to
     if (const char *fp = getenv("DEMON_FORCE_PLAN")) {
@@ -866,7 +844,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                     return;
                 }
             } else if (tile >= 0 && tile < TILE_COUNT && L->Mpad % conv_tile_bm(tile) == 0) {
-                run_mfma(a, ConvPlan{tile, clamp_split(ks < 1 ? 1 : (ks % 1000 > L->Kpad / 16 ? L->Kpad / 16 + ks / 1000 * 1000 : ks))}, L->ncls, s);
+                run_mfma(a, ConvPlan{tile, clamp_split(ks < 1 ? 1 : std::min(ks % 1000, L->Kpad / 16))}, L->ncls, s);
                 return;
             }
         }
@@ -1078,22 +1056,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
         if (ms < best) { best = ms; best_t = Layer::Tuned{cd.kind, cd.tile, cd.ksplit}; }
         return ms;
     };
-    // split-K candidates of the im2col / streaming / fragment-tiled kernels exist twice: with the reduce launch and with the K
-    // slices combined inside the launch (ksplit + 1000).  The second form is measured for the fastest few of the first.
-    std::vector<std::pair<float, size_t>> split_ms;
-    for (size_t i = 0; i < cands.size() && !failed; ++i) {
-        const float ms = measure(cands[i]);
-        if ((cands[i].kind == 0 || cands[i].kind == 4 || cands[i].kind == 5) && cands[i].ksplit > 1) split_ms.push_back({ms, i});
-    }
-    std::sort(split_ms.begin(), split_ms.end());
-    // opt-in only (option "tune_in_launch_splitk"): the in-launch form orders its slab stores against the ticket with write-through
-    // stores + s_waitcnt and a relaxed atomic, not with a formal release / acquire pair; no shipped plan uses it
-    for (size_t q = 0; c->opt_tune_fixup && q < split_ms.size() && q < 6 && !failed; ++q) {
-        Cand cd = cands[split_ms[q].second];
-        cd.ksplit += 1000;
-        cands.push_back(cd);
-        measure(cd);
-    }
+    for (size_t i = 0; i < cands.size() && !failed; ++i) measure(cands[i]);
     if (failed) { hipEventDestroy(e0); hipEventDestroy(e1); return DEMON_ERR_HIP; }
     if (const char *pk = getenv("DEMON_TUNE_PICK")) {  // test hook: deterministic choice = candidate index
         const Cand &cd = cands[(size_t)atoi(pk) % cands.size()];
@@ -1685,21 +1648,12 @@ void enqueue_sequence(demon_ctx *c, int kind, int n, int iterations, hipStream_t
 }
 
 // one hipGraph per (sequence, batch, iterations): the whole kernel chain becomes a single launch
-// The arrival counters of the in-launch split-K are zero between launches only as long as every launch runs to its end; after a
-// failed launch (or before a tuning session that may abort candidates) they are put back to zero explicitly.
-void reset_splitk_tickets(demon_ctx *c)
-{
-    for (float *ws : {c->d_ws, c->d_ws_side})
-        if (ws) hipMemsetAsync(ws + kSplitKWorkspaceFloats, 0, sizeof(unsigned) * kSplitKTickets, c->stream);
-}
-
 int run_sequence(demon_ctx *c, int kind, int n, int iterations)
 {
     c->err.clear();
     if (!c->opt_hipgraph) {
         enqueue_sequence(c, kind, n, iterations, c->stream);
         if (hipGetLastError() != hipSuccess || !c->err.empty()) {
-            reset_splitk_tickets(c);
             if (c->err.empty()) c->err = "kernel launch failed";
             return DEMON_ERR_HIP;
         }
@@ -2186,7 +2140,6 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
     if (!strcmp(key, "reuse_image_features")) { c->opt_reuse_image = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "fused_pairs")) { c->opt_fused_pairs = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "fused_inputs")) { c->opt_fused_inputs = value ? 1 : 0; return DEMON_OK; }
-    if (!strcmp(key, "tune_in_launch_splitk")) { c->opt_tune_fixup = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "side_branches")) { c->opt_side_branches = (value && c->side_stream && c->d_ws_side != c->d_ws) ? 1 : 0; return DEMON_OK; }
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }
@@ -2269,7 +2222,8 @@ int autotune_fused_pair(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
         if (!ok) failed = true;
         return ms;
     };
-    const Layer::Tuned before = Ly->tuned.count(n) ? Ly->tuned[n] : Layer::Tuned{1, 0, 0};
+    const bool had = Ly->tuned.count(n) > 0;
+    const Layer::Tuned before = had ? Ly->tuned[n] : Layer::Tuned{14, 0, 1};
     Ly->tuned[n] = Layer::Tuned{12, 0, 1};
     const float two = measure(false);
     const float one = measure(true);
@@ -2277,8 +2231,10 @@ int autotune_fused_pair(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
     hipEventDestroy(e1);
     if (failed) return DEMON_ERR_HIP;
     if (one <= two) {
-        if (before.kind != 12) Ly->tuned[n] = before;
-        else Ly->tuned.erase(n);   // the fused launch wins and no other entry was measured: the heuristics serve the (unused) k x 1 layer
+        // the fused launch wins: the k x 1 layer gets back the entry it had, or -- when nothing else was measured for it -- the explicit
+        // marker kind 14 ("pair runs fused at this batch size; alone, the layer is served by the heuristics"), so that nearest_tuned()
+        // cannot pick up another batch size's kind 12 for a pair that just measured faster as one launch
+        Ly->tuned[n] = (had && before.kind != 12) ? before : Layer::Tuned{14, 0, 1};
     }
     return DEMON_OK;
 }
@@ -2290,7 +2246,6 @@ int demon_autotune(demon_ctx *c, int n)
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);  // captured launches embed the old choices
     c->graphs.clear();
     prepare_stream_weights(c);
-    reset_splitk_tickets(c);
     // DEMON_TUNE_ONLY=<substring>: re-tune only the layers whose name contains it (the others keep their installed plan entries)
     const char *only = getenv("DEMON_TUNE_ONLY");
     for (auto &L : c->layers) {
@@ -2334,9 +2289,12 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
     // 11 = weight-streaming dense layer (dense_stream.hip; tile 0 / 1 = default / non-temporal weight loads)
     // 12 = the blocks' first layer with the weights in registers (conv_thin.hip; tile 0); its pair then runs as two launches
     // 13 = 1 x 7 / 1 x 9 stride-2 conv with <= 32 channels, whole reduction out of LDS (conv_row.hip; tile 0)
-    if (kind < 0 || kind > 13 || kind == 2 || kind == 9 || tile < 0 ||
+    // 14 = marker on the k x 1 layer of a conv_pair.hip pair: the fused launch was measured faster at this batch size (the layer alone: heuristics)
+    if (kind < 0 || kind > 14 || kind == 2 || kind == 9 || tile < 0 ||
         tile >= (kind >= 12 ? 1 : kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
+    if (kind != 1 && ksplit >= 1000)   // (until round 3 "+ 1000" on kinds 0 / 4 / 5 selected a split-K form that no longer exists)
+        return fail(c, DEMON_ERR_INVALID, "ksplit >= 1000 is only meaningful for the patch-staged kernel (pixel-tile shape)");
     for (auto &L : c->layers)
         if (L->name == layer_name) {
             if (kind == 0 && L->Mpad % conv_tile_bm(tile)) return fail(c, DEMON_ERR_INVALID, "tile does not divide Cout");

@@ -3,10 +3,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
 namespace demon {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one bit per device and kernel instance (a `static` of the
+// templated launcher).  Two threads racing on the same bit both set the attribute, which is harmless.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> done{0};
+    template <class F>
+    bool ensure(F &&configure)
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return configure();
+        if (done.load(std::memory_order_acquire) >> dev & 1ull) return true;
+        if (!configure()) return false;
+        done.fetch_or(1ull << dev, std::memory_order_release);
+        return true;
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // A view of `C` channels [c0, c0+C) inside an NCHW device buffer that has `Ctot` channels per
@@ -108,86 +125,18 @@ struct ConvArgs {
     long cls_w_stride;  // Kpad*Mpad
     float *ws;          // split-K workspace [cls][slice][Mpad][P]
     int ksplit;         // number of K slices (1 = fused epilogue)
-    unsigned *tickets;  // split-K combined inside the launch: arrival counters, one per (tile, epilogue wave), all zero between
-                        // launches; null: partial sums are combined by conv_splitk_reduce (a second launch)
     int xcd;            // 1: XCD-aware tile order (xcd_tile)
     long out_plane;     // elements between output channel planes (Ho*Wo unless the buffer is padded)
     unsigned long long *tl;  // timeline records (diagnostic build), else null
 };
 
-// ---- split-K combined inside the launch ---------------------------------------------------------------------------------------
-// Every wave parks its raw accumulators in a slab of its own -- the registers as they are, [block][r / 4][lane][4], 16-byte
-// WRITE-THROUGH (sc1) stores: the XCDs' L2s are not coherent with each other and a release fence (buffer_wbl2) per wave was
-// measured 2-8x slower than the reduce launch it replaces -- drains them, and takes a ticket of its (tile, wave) slot.  The wave
-// that draws the last ticket drops its CU's L1 (agent-scope acquire), adds up all slices IN SLICE ORDER (so the result does not
-// depend on who arrives last and equals what conv_splitk_reduce produces) and runs the ordinary epilogue.  No workgroup barrier.
-// The ticket word is put back to zero by the last arriver, so the counters need no memset node per launch (they are zeroed once,
-// when the workspace is allocated).
-constexpr long kSplitKWorkspaceFloats = 16l << 20;  // 64 MiB of partial sums ...
-constexpr long kSplitKTickets = 1l << 18;           // ... followed by this many ticket words
-
-typedef unsigned splitk_u32x4 __attribute__((ext_vector_type(4)));
-typedef float splitk_f32x4 __attribute__((ext_vector_type(4)));
-
-// floats of workspace the in-launch form needs (the launchers fall back to the reduce launch when it does not fit)
-inline long splitk_slab_floats(long tiles, int waves, int tm, int tn, int ncls, int ksplit) { return tiles * waves * tm * tn * 1024 * ncls * ksplit; }
-
-// ew = waves of the workgroup that reach the epilogue, wave = this wave's index among them; false: not the last arriver (done)
-template <int TM, int TN, class V>
-__device__ __forceinline__ bool splitk_combine_in_launch(V (&acc)[TM][TN], float *ws, unsigned *tickets, int ksplit, int cls, int zs, int ew, int wave)
-{
-    constexpr int SLAB = TM * TN * 1024;  // floats per (tile, wave)
-    const long ntiles = (long)gridDim.x * gridDim.y, tile = (long)blockIdx.y * gridDim.x + blockIdx.x;
-    const unsigned slice_bytes = (unsigned)(ntiles * ew * SLAB * 4);
-    const unsigned lane = threadIdx.x & 63;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(ws, 0, (int)(kSplitKWorkspaceFloats * 4), 0x00020000);
-    const unsigned base = (unsigned)(cls * ksplit) * slice_bytes + (unsigned)((tile * ew + wave) * SLAB * 4) + lane * 16;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const splitk_f32x4 v = {acc[i][j][4 * rb], acc[i][j][4 * rb + 1], acc[i][j][4 * rb + 2], acc[i][j][4 * rb + 3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(splitk_u32x4, v), rsrc,
-                                                       base + (unsigned)zs * slice_bytes + ((i * TN + j) * 4 + rb) * 1024, 0, /*sc1*/ 16);
-            }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's slab has left
-    unsigned *ticket = tickets + ((long)cls * ntiles + tile) * ew + wave;
-    unsigned t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t != (unsigned)ksplit - 1u) return false;
-    if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    for (int z = 0; z < ksplit; ++z) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    const splitk_f32x4 v = __builtin_bit_cast(splitk_f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                        rsrc, base + (unsigned)z * slice_bytes + ((i * TN + j) * 4 + rb) * 1024, 0, 0));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * rb + e] += v[e];
-                }
-    }
-    return true;
-}
+constexpr long kSplitKWorkspaceFloats = 16l << 20;  // 64 MiB of partial sums per stream
 
 enum ConvTile { TILE_128x128 = 0, TILE_64x128, TILE_32x128, TILE_64x64, TILE_32x64, TILE_32x32, TILE_128x32, TILE_64x32, TILE_COUNT };
 struct ConvPlan { int tile; int ksplit; };
 
-// the launchers return true when the K slices were combined inside the launch (a.tickets set, enough ticket words), false when a
-// conv_splitk_reduce launch followed or there was nothing to combine
-bool launch_conv_mfma(const ConvArgs &a, ConvPlan plan, int nclasses, hipStream_t stream);
+// ksplit > 1: the K slices' partial sums go to the workspace and a conv_splitk_reduce launch follows
+void launch_conv_mfma(const ConvArgs &a, ConvPlan plan, int nclasses, hipStream_t stream);
 ConvPlan choose_conv_plan(int Mpad, long pixels, int nclasses, int Kpad, long ws_floats);
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);
@@ -214,7 +163,7 @@ int stream_variant_kw(int v);  // K-splitting wave groups inside a workgroup (1:
 int stream_variant_bm(int v);
 int stream_variant_bn(int v);
 void launch_stream_repack(float *wf, const float *wp, int ncls, int K, int Mpad, long cls_w_stride, hipStream_t s);
-bool launch_conv_stream(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
+void launch_conv_stream(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
 // k x 1 + 1 x k stride-1 pair as one chained launch of a variant whose tile holds all channels of whole rows; false: not applicable
 bool launch_conv_stream_chain(const StreamArgs &s1, const StreamArgs &s2, int variant, hipStream_t stream);
 
@@ -223,7 +172,7 @@ constexpr int FRAG_VARIANTS = 22;  // (waves along Cout, waves along pixels, row
 int frag_variant_bm(int v);
 int frag_variant_bn(int v);
 int frag_variant_kw(int v);  // K-splitting wave groups inside a workgroup (1: none)
-bool launch_conv_frag(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
+void launch_conv_frag(const StreamArgs &s, int variant, int ksplit, int nclasses, hipStream_t stream);
 bool launch_conv_frag_chain(const StreamArgs &s1, const StreamArgs &s2, int variant, hipStream_t stream);
 
 // ---- patch-staged convolution (conv_patch.hip) ---------------------------------------------------------
@@ -341,7 +290,7 @@ bool wino1d_variant_ok(int kind, int v);
 bool wino1d_plan_geometry(Wino1Args &a, int kind, int variant, int axis, int n);
 long wino1d_workgroups(const Wino1Args &a, int variant);
 void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, int cross, hipStream_t s);
-void launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream);
+bool launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream);   // false: nothing was launched
 
 // ---- weight-streaming dense layer at small batch (dense_stream.hip): dense5 (v2), motion_fc1 -----------------------------------------------
 struct DenseArgs {
@@ -386,7 +335,7 @@ struct RowArgs {
     long in_n_stride;
     int Cout, Ho, Wo;
     long out_n_stride, out_plane;
-    int pad, act, num_cus;
+    int pad, act;
     int tiles_y, tiles_x;   // (set by the launcher)
 };
 bool conv_row_shape_ok(int kh, int kw, int sh, int sw, int ph, int pw, int Cin, int Mpad, int W, int Wo);

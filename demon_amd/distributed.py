@@ -44,9 +44,12 @@ class NativeComm:
         self.handle = None
         payload = None
         if rank == 0:
-            buf = ctypes.create_string_buffer(128)
-            rc = self.lib.demon_comm_get_unique_id(buf)
-            payload = buf.raw if rc == 0 else b"!demon_comm_get_unique_id failed (%d): %s" % (rc, self.lib.demon_last_error(None))
+            try:   # whatever goes wrong here, rank 0 still ships a marker: the other ranks are about to block in `exchange`
+                buf = ctypes.create_string_buffer(128)
+                rc = self.lib.demon_comm_get_unique_id(buf)
+                payload = buf.raw if rc == 0 else b"!demon_comm_get_unique_id failed (%d): %s" % (rc, self.lib.demon_last_error(None) or b"")
+            except Exception as e:
+                rc, payload = -1, b"!" + repr(e).encode(errors="replace")
             if rc != 0 and len(payload) == 128:
                 payload += b" "   # an id is exactly 128 bytes, the marker never is
         uid = exchange(payload) if world > 1 else payload
@@ -125,17 +128,22 @@ def distribute_weights(ctx, host_weights, rank, world, route="rccl", comm=None):
         if own:
             # every rank must end up on the same route.  NativeComm's id exchange is unconditional (rank 0 ships an error marker
             # instead of an id when it has none), so all ranks reach the agreement below having run the same collectives
+            nranks = None
             try:
                 comm = NativeComm(rank, world, ctx.device)
+                nranks = comm.count()   # (inside the try: a failure on ONE rank must reach the consensus below, not raise past it)
                 ok = 1
-            except Exception as e:   # librccl missing, rank 0 without an id, or ncclCommInitRank failed
+            except Exception as e:   # librccl missing, rank 0 without an id, ncclCommInitRank or ncclCommCount failed
+                if comm is not None:
+                    comm.close()
                 comm, ok, note = None, 0, " (native RCCL init failed on rank %d: %s)" % (rank, e)
             if not all_ranks_ok(ok, ctx.device):
                 if comm is not None:
                     comm.close()
                 dt, desc = distribute_weights(ctx, host_weights, rank, world, route="torch-gpu")
                 return dt, desc + " [fallback]" + note
-        nranks = comm.count()
+        else:
+            nranks = comm.count()
         if rank == 0:
             ctx.set_weights(host_weights)      # TF layouts -> packed slab, on the root only
         t0 = time.perf_counter()

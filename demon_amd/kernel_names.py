@@ -12,9 +12,9 @@ def frag_variants():
     """variant index -> (WM, WN, TM, TN, KS, KW), read from the dispatch switch in csrc/conv_frag.hip"""
     src = open(os.path.join(CSRC, "conv_frag.hip")).read()
     table = {}
-    for m in re.finditer(r"case (\d+): launch_frag_variant<([\d, ]+)>", src):
+    for m in re.finditer(r"case (\d+): launch_frag_instance<([\d, ]+)>", src):
         table[int(m.group(1))] = tuple(int(x) for x in m.group(2).split(","))
-    m = re.search(r"default: launch_frag_variant<([\d, ]+)>", src)
+    m = re.search(r"default: launch_frag_instance<([\d, ]+)>", src)
     if m:
         table[max(table) + 1] = tuple(int(x) for x in m.group(1).split(","))
     return table

@@ -92,9 +92,7 @@ int demon_set_weights_blob_device(demon_ctx *ctx, const void *device_blob, int64
  * they do not depend on (fork / join by events, captured into the same hipGraph) -- same kernels, same results;
  * "fused_pairs" 0/1 (default 1): the first k x 1 / 1 x k pair (conv1, 6 input channels, the largest intermediate) as one launch,
  * the intermediate staying in LDS (conv_pair.hip) -- same arithmetic, other summation order;
- * "fused_inputs" 0/1 (default 1): the extra-input assembly of the iterative blocks / the refinement input as one launch each;
- * "tune_in_launch_splitk" 0/1 (default 0): demon_autotune may also select "split-K combined inside the launch" (experimental:
- * ordered by write-through stores + a relaxed ticket, not by a formal release / acquire pair; no shipped plan uses it) */
+ * "fused_inputs" 0/1 (default 1): the extra-input assembly of the iterative blocks / the refinement input as one launch each */
 int demon_set_option(demon_ctx *ctx, const char *key, int value);
 /* Times every applicable kernel variant (im2col / patch-staged, tile shape, split-K) of every layer at batch n on
  * this GPU and keeps the fastest per layer (~1 s; results do not change, only launch plans). */
@@ -110,8 +108,9 @@ int demon_autotune(demon_ctx *ctx, int n);
  *   13 1 x 7 / 1 x 9 stride-2 conv with at most 32 channels on both sides, whole reduction out of LDS (conv_row.hip; tile 0),
  *        3 small-Cout VALU kernel, 4 register-streaming kernel (conv_stream.hip), 5 fragment-tiled kernel (conv_frag.hip),
  *        6 / 7 on the k x 1 layer of a stride-1 pair: the pair runs as ONE chained launch of conv_frag / conv_stream variant `tile`;
- *   tile = tile / variant id of that kernel; ksplit = K slices (kinds 0 / 4 / 5: + 1000 = slices combined inside the launch
- *   instead of by a reduce launch).  demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
+ *        14 marker on the k x 1 layer of a conv_pair.hip pair: the fused launch measured faster at this batch size;
+ *   tile = tile / variant id of that kernel; ksplit = K slices across workgroups, combined by a conv_splitk_reduce launch.
+ *   demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
 int demon_num_layers(const demon_ctx *ctx);
 int demon_plan_get(const demon_ctx *ctx, int n, int layer_index, char *name, int name_cap, int *kind, int *tile, int *ksplit);
 int demon_plan_set(demon_ctx *ctx, int n, const char *layer_name, int kind, int tile, int ksplit);
