@@ -6,15 +6,22 @@
               --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic pairs already resident in HBM (BASELINE.json
-configs[2]: batch 32 per GPU, full pipeline, hipGraph on).  Pairs are independent, so ranks shard the
+configs[2]: batch 32 per GPU, full pipeline, hipGraph on) = ONE hipGraph launch.  Steps go round robin over `--lanes` contexts
+of the rank's GPU (demon_amd/lanes.py: own stream, activation arena, resident batch and graph each), so up to that many steps are
+in flight and one pass fills the SIMDs another leaves idle at its kernel boundaries; `single_lane` in the same line is the rate of
+the same K steps on one lane (one step at a time).  Pairs are independent, so ranks shard the
 batch with no data-path collective (weak scaling: 32 pairs per GPU, configs[3] = 8 x 32); the only
 collective is one RCCL broadcast of the 183 MB weight blob at start-up, outside the timed region.
 Rank 0 prints ONE JSON line.  `roofline` = the single kernel (template instance) with the largest share of the pass by its own time
 (rocprofv3's convention: split-K reduce launches listed beside it), `roofline_worst` = the kernel with >= 5 % of the pass that is
 furthest below its roofline, `roofline_family` = all conv / deconv / dense launches; all timed per launch with HIP events on the
-context stream, with rocprofv3's average of the same kernel next to it when profiles/ holds one for these kernel sources;
+context stream, with rocprofv3's average of the same kernel next to it when profiles/ holds one for these kernel sources.
+In all three, `achieved` / `frac` count the multiply-adds the MATRIX PIPE EXECUTES (<= peak by construction: the minimal-filtering
+kernels compute the direct convolution's sums with fewer products), `algorithmic_achieved` / `algorithmic_frac` price the
+direct convolution's 2*MAC over the same time; `pipeline_mfma_frac` (algorithmic, whole pass) has
+`pipeline_mfma_executed_frac` beside it.
 `cpu_baseline` = the CPU oracle ("TF-CPU-equivalent" PyTorch-CPU restatement) on this box's host cores, rank 0 / N=1 only;
-`extra` = the PCIe-inclusive host-to-host rate.
+`extra` = the PCIe-inclusive host-to-host rates (synchronous pageable copies, and the pinned two-context Pipeline).
 """
 import argparse
 import json
@@ -152,6 +159,10 @@ def main():
                     help="N > 1: rccl = one ncclBroadcast of the packed weight slab through the C ABI (default); torch = "
                          "torch.distributed.broadcast of the TF-layout blob")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host (H2D + kernels + D2H) measurement")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="contexts per GPU the steps go round (each with its own stream, arena, resident batch and hipGraph): that many "
+                         "steps are in flight at a time.  Default 0 = measure 1 .. 5 lanes at start-up (untimed set-up) and keep the best; "
+                         "1 = one step at a time")
     args = ap.parse_args()
 
     import torch
@@ -160,6 +171,9 @@ def main():
     height, width, def_batch, gflop_pair, wl_desc = WORKLOADS[args.workload]
     if args.batch <= 0:
         args.batch = def_batch
+    auto_lanes = args.lanes <= 0
+    if auto_lanes:
+        args.lanes = 3 if args.workload == "hires" else 5
     boot_only = args.workload == "bootstrap"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,7 +213,6 @@ def main():
     # each rank owns its own shard of the global batch (rank r: pairs [r*B, (r+1)*B))
     pair, img2_2 = make_inputs(args.batch, seed=rank, height=height, width=width)
     n = ctx.upload_inputs(pair, img2_2)
-    step = (lambda: ctx.run_bootstrap(n)) if boot_only else (lambda: ctx.run_full(n, args.iterations))
     t0 = time.perf_counter()
     if args.reuse_image_features:
         ctx.set_option("reuse_image_features", 1)
@@ -207,38 +220,64 @@ def main():
     if not args.no_autotune:
         # per-layer kernel / tile / split-K selection (untimed set-up): the plan shipped in demon_amd/tuned/ for this
         # workload (measured once on an MI355X by tools/tune.py) or, when there is none, measured now
-        src_n = 0 if args.retune else ctx.load_tuned_plan(n)
+        src_n = 0 if args.retune else ctx.load_tuned_plan(n, lanes=args.lanes)
         if src_n:
             plan_src = "demon_amd/tuned" if src_n == n else "demon_amd/tuned (plan of batch %d, nearest tuned size)" % src_n
         else:
             ctx.autotune(n)
             plan_src = "autotune at start-up"
+    # the lanes: lane 0 is this rank's context; the others get the packed weights device to device and a batch of their own
+    # (untimed set-up, like the plan: it also captures every lane's forward graph)
+    from demon_amd.lanes import LaneGroup
+    group = LaneGroup(first=ctx, lanes=args.lanes, batch=args.batch, height=height, width=width, device=local_rank, version=version, plan_batch=n)
+    for li, c in enumerate(group.ctxs[1:], 1):
+        if args.reuse_image_features:
+            c.set_option("reuse_image_features", 1)
+        c.upload_inputs(*make_inputs(args.batch, seed=1000 * li + rank, height=height, width=width))
+    group.run_resident(n, len(group), args.iterations, boot_only)
+    group.synchronize()
+    lane_rates = None
+    if auto_lanes:   # which lane count pays off depends on the runtime's stream -> hardware-queue mapping in THIS process: measured
+        lane_rates = group.calibrate(n, args.iterations, boot_only)
+        args.lanes = len(group)
     t_tune = time.perf_counter() - t0
 
     def barrier():
         if distributed:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(run_steps, sync):
+        """W untimed + exactly K timed steps, bracketed by a barrier + device synchronisation on both sides; MAX over the ranks"""
+        run_steps(args.warmup)
+        sync()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        sync()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
+    elapsed = timed(lambda k: group.run_resident(n, k, args.iterations, boot_only), group.synchronize)
     out = ctx.download_outputs(n, with_depth0=not boot_only)
     finite = all(np.isfinite(v).all() for v in out.values())
+    for c in group.ctxs[1:]:
+        finite = finite and all(np.isfinite(v).all() for v in c.download_outputs(n, with_depth0=not boot_only).values())
+    group.close()          # lane 0 = ctx stays (and gets its side branches back)
+    if args.lanes > 1 and not args.no_autotune and not args.retune:
+        ctx.load_tuned_plan(n)   # ... and the plan tuned for one pass at a time, when the lanes ran a throughput-mode plan
+    # the same K steps one at a time on one lane (round 1-3's protocol), for comparison
+    elapsed_single = elapsed if args.lanes == 1 else timed(
+        lambda k: [ctx.run_bootstrap(n) if boot_only else ctx.run_full(n, args.iterations) for _ in range(k)], ctx.synchronize)
+    out1 = ctx.download_outputs(n, with_depth0=not boot_only)
+    lanes_equal_single = all(np.array_equal(out[k], out1[k]) for k in out)
 
     result = None
     if rank == 0:
@@ -253,12 +292,17 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_desc % ((args.batch,) if boot_only else (args.batch, args.iterations)),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "iterations": args.iterations,
+                       "lanes": args.lanes, "steps_in_flight_per_gpu": args.lanes,
+                       "lanes_calibration_pairs_per_s": {str(k): round(v, 1) for k, v in lane_rates.items()} if lane_rates else None,
                        "sharding": "independent pairs per rank, no data-path collective",
                        "weights": "synthetic He-normal seed 1; %s, %.1f ms (untimed)" % (bcast_desc, 1e3 * t_bcast),
                        "weights_broadcast_ms": round(1e3 * t_bcast, 2), "weights_broadcast_route": bcast_route,
                        "rccl_nranks": rccl_nranks,
                        "launch_plan": plan_src, "plan_setup_s": round(t_tune, 2)},
             "outputs_finite": bool(finite),
+            "single_lane": {"pairs_per_s": pairs / elapsed_single, "ms_per_step": 1e3 * elapsed_single / args.steps,
+                            "lane0_outputs_equal": bool(lanes_equal_single),
+                            "note": "the same K steps one at a time on one lane (side branches of the pass on a second stream, as in rounds 1-3)"},
         }
         if gflop_pair:
             result["pipeline_mfma_frac"] = value / world * gflop_pair * 1e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12)
@@ -290,7 +334,7 @@ def main():
                 import re
                 if tag.startswith("wino_deconv"):
                     return 9.0 / 16.0            # F(2,2) x F(2,2) per sub-pixel class
-                m = re.match(r"wino1d<t(\d+)", tag)
+                m = re.match(r"(?:wino1d|conv_row<32x128,|wino1d_chain)<?t(\d+)", tag)
                 if m:
                     taps = int(m.group(1))
                     return 4.0 / 6.0 if taps == 3 else (taps + 2.0) / (2.0 * taps)   # F(2,3); polyphase F(2,re) + F(2,ro), stride 2
@@ -298,30 +342,33 @@ def main():
 
             def roofline_entry(tag):
                 k = by_kernel[tag]
-                achieved = k["flops"] / (k["ms"] * 1e-3) / 1e12
+                share = executed_share(tag)
+                algorithmic = k["flops"] / (k["ms"] * 1e-3) / 1e12
+                achieved = algorithmic * share     # what the matrix pipe executes: <= peak by construction
                 e = {
                     "kernel": rocprof_kernel_name(tag), "tag": tag,
                     "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                    "algorithmic_achieved": algorithmic, "algorithmic_frac": algorithmic / PEAK_FP32_MFMA_TFLOPS,
+                    "mfma_flops_executed_per_algorithmic": share,
                     "algorithmic_bytes_per_launch": k["bytes"] / k["launches"], "flops_per_launch": k["flops"] / k["launches"],
                     "launches": k["launches"], "avg_launch_ms": k["ms"] / k["launches"],
                     "kernel_time_share": k["ms"] / total_ms,
                     "splitk_reduce": {"launches": k["splitk_launches"],
                                       "avg_ms": k["reduce_ms"] / k["splitk_launches"] if k["splitk_launches"] else 0.0,
-                                      "frac_with_reduce": k["flops"] / ((k["ms"] + k["reduce_ms"]) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
+                                      "frac_with_reduce": share * k["flops"] / ((k["ms"] + k["reduce_ms"]) * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS},
                     "timing": "hip events around each launch on the context stream, launches run one after the other (eager), mean of 3 "
                               "passes; kernel only -- the conv_splitk_reduce launch that follows some launches is timed separately (splitk_reduce)",
                 }
-                if executed_share(tag) != 1.0:   # `achieved` prices the ALGORITHMIC flops (direct convolution), as every other entry
-                    e["mfma_flops_executed_per_algorithmic"] = executed_share(tag)
-                    e["executed_frac"] = e["frac"] * executed_share(tag)
+                e["flops_executed_per_launch"] = share * k["flops"] / k["launches"]
+                if share != 1.0:
                     e["note"] = ("minimal-filtering kernel: the matrix pipe executes %.4f of the direct convolution's multiply-adds; `achieved` / `frac` "
-                                 "are algorithmic flops over time (they may exceed what a direct kernel could reach), `executed_frac` is the matrix-pipe share") % executed_share(tag)
+                                 "count the executed ones (a roofline fraction, <= 1), `algorithmic_*` price the direct convolution's flops over the same time") % share
                 rp = rocprof.get(tag)
                 if rp:   # the other clock: rocprofv3 --kernel-trace --stats of this command (graph replay), same kernel sources
                     e["rocprof_avg_launch_ms"] = rp["avg_ms"]
                     e["rocprof_calls"] = rp["calls"]
-                    e["rocprof_frac"] = k["flops"] / k["launches"] / (rp["avg_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+                    e["rocprof_frac"] = share * k["flops"] / k["launches"] / (rp["avg_ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
                     e["rocprof_source"] = rp["source"]
                 return e
 
@@ -332,18 +379,21 @@ def main():
             # `roofline_family` = all contraction launches together
             result["roofline"] = roofline_entry(dom_tag)
             big = [t for t, k in contraction.items() if k["ms"] / total_ms >= 0.05]
-            worst_tag = min(big, key=lambda t: contraction[t]["flops"] / contraction[t]["ms"]) if big else dom_tag
+            worst_tag = min(big, key=lambda t: executed_share(t) * contraction[t]["flops"] / contraction[t]["ms"]) if big else dom_tag
             result["roofline_worst"] = roofline_entry(worst_tag)
-            fam_achieved = flops / (ms * 1e-3) / 1e12
+            fam_algorithmic = flops / (ms * 1e-3) / 1e12
+            flops_executed = sum(r["flops"] * executed_share(r["kernel"].split("+")[0]) for r in conv)
+            fam_achieved = flops_executed / (ms * 1e-3) / 1e12
+            result["pipeline_mfma_executed_frac"] = result["pipeline_mfma_frac"] * flops_executed / flops
             result["roofline_family"] = {
                 "kernel": "all conv / deconv / dense launches (wino_deconv, wino1d, conv_frag, conv_frag_chain, conv_stream, conv_stream_chain, conv_patch, deconv4, conv_pair, conv_thin, conv_row, dense_stream, conv_mfma, conv_small kernels)",
-                "executed_frac": sum(r["flops"] * executed_share(r["kernel"].split("+")[0]) for r in conv) / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "note": "`achieved` / `frac` price the ALGORITHMIC flops (2 * MAC of the direct convolutions, BASELINE.md section 2); the minimal-filtering kernels (conv_wino.hip) execute fewer multiply-adds for the same sums: `executed_frac` is the matrix-pipe share",
+                "note": "`achieved` / `frac` count the multiply-adds the matrix pipe executes (the minimal-filtering kernels of conv_wino.hip / conv_row.hip compute the same sums with fewer products); `algorithmic_*` price 2 * MAC of the direct convolutions (BASELINE.md section 2) over the same time",
                 "bound": "mfma", "achieved": fam_achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": fam_achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "algorithmic_achieved": fam_algorithmic, "algorithmic_frac": fam_algorithmic / PEAK_FP32_MFMA_TFLOPS,
+                "mfma_flops_executed_per_algorithmic": flops_executed / flops,
                 "algorithmic_bytes_per_launch": sum(r["bytes"] for r in conv) / len(conv),
                 "launches": len(conv), "splitk_reduce_launches": sum(1 for r in conv if "+splitk" in r["kernel"]),
-                "splitk_combined_in_launch": sum(1 for r in conv if "+fixup" in r["kernel"]),
                 "avg_launch_ms": ms / len(conv), "flops_per_launch": flops / len(conv),
                 "gflop_per_pair_launched": flops / n / 1e9, "kernel_time_share": ms / total_ms,
             }
@@ -394,7 +444,29 @@ def main():
             out_b = sum(v.nbytes for v in out.values())
             result["extra"] = {"end_to_end_pairs_per_s": n / dt, "end_to_end_ms_per_step": 1e3 * dt,
                                "h2d_bytes_per_step": in_b, "d2h_bytes_per_step": out_b,
-                               "note": "demon_full from / to pageable numpy buffers on rank 0 (PCIe-inclusive; not the metric)"}
+                               "note": "demon_full from / to pageable numpy buffers on rank 0, synchronous copies (PCIe-inclusive; not the metric)"}
+            if args.workload in ("full", "v2"):
+                # the host-to-host rate a batch-streaming caller gets (examples/evaluation.py:225-256 fed in batches): two contexts /
+                # streams fed alternately from page-locked host arrays, the copies of one batch under the kernels of the other
+                # (demon_amd/pipeline.py); also never `value`
+                from demon_amd.pipeline import Pipeline
+                pipe = Pipeline(host_weights, batch=n, height=height, width=width, device=local_rank, version=version, contexts=5, calibrate=True)
+                try:
+                    hb = pipe.buffers(8 * n)
+                    try:
+                        for i in range(8):
+                            hb.image_pair[i * n:(i + 1) * n] = pair
+                            hb.image2_2[i * n:(i + 1) * n] = img2_2
+                        r = pipe.throughput(hb, args.iterations, repeats=2)
+                        same = all(np.array_equal(hb.out[k][:n], out[k]) for k in hb.out)
+                    finally:
+                        hb.release()
+                finally:
+                    pipe.close()
+                result["extra"]["pipelined"] = dict(r, outputs_equal_resident_run=bool(same), frac_of_resident=r["pairs_per_s"] / (value / world),
+                                                    lanes_calibration_pairs_per_s={str(k): round(v, 1) for k, v in (pipe.lane_rates or {}).items()},
+                                                    note="demon_amd.pipeline.Pipeline: lanes fed round robin from page-locked host arrays, "
+                                                         "asynchronous H2D / D2H under the other lanes' kernels; 8 batches per pass")
         if not args.no_cpu_baseline and world == 1 and args.workload == "full":
             result["cpu_baseline"] = cpu_baseline(host_weights)
     ctx.close()

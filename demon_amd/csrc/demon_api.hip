@@ -156,6 +156,9 @@ struct demon_ctx {
     float *d_ws = nullptr;  // split-K workspace
     float *d_ws_side = nullptr;  // split-K workspace of the side branch (runs concurrently with the main one)
     hipStream_t side_stream = nullptr;
+    std::vector<hipStream_t> tune_streams;   // throughput-mode autotune (option tune_lanes): concurrent replays need streams of their own
+    std::vector<hipEvent_t> tune_events;
+    int opt_tune_lanes = 1;
     std::vector<hipEvent_t> events;  // fork / join events, one per use inside a sequence
     int opt_side_branches = 1;
     int opt_fused_pairs = 1;  // conv_pair.hip for the pairs conv_pair_applies() selects
@@ -916,6 +919,55 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
     run_mfma(a, plan, L->ncls, s);
 }
 
+// Wall time (ms) of `body` -- captured five times into one hipGraph, like the real sequences run, so that the host-side planning of an
+// eager launch does not leak into the comparison -- replayed on the context stream.  Option "tune_lanes" = L > 1 ("throughput
+// mode"): L instances of the graph replay CONCURRENTLY on L streams and the time until all are done is returned.  That is the cost
+// of a candidate when several passes are in flight on the GPU (demon_amd/lanes.py): a kernel that is fastest alone because it spreads
+// over every CU, or splits K into many short workgroups plus a reduce launch, may lose to one that finishes its work in fewer
+// SIMD cycles.  (The instances write the same outputs and share the split-K workspace: timing runs only.)
+float time_replay(demon_ctx *c, const std::function<void()> &body, bool &failed)
+{
+    const int lanes = std::max(1, std::min(c->opt_tune_lanes, 8));
+    while ((int)c->tune_streams.size() < lanes - 1) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { failed = true; return 1e30f; }
+        c->tune_streams.push_back(st);
+    }
+    while ((int)c->tune_events.size() < lanes + 1) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { failed = true; return 1e30f; }
+        c->tune_events.push_back(e);
+    }
+    hipEvent_t e0 = c->tune_events[0], e1 = c->tune_events[1];
+    hipGraph_t graph = nullptr;
+    std::vector<hipGraphExec_t> execs((size_t)lanes, nullptr);
+    bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+        for (int i = 0; i < 5; ++i) body();
+        ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess;
+        for (int i = 0; ok && i < lanes; ++i) ok = hipGraphInstantiate(&execs[i], graph, nullptr, nullptr, 0) == hipSuccess;
+    }
+    auto stream_of = [&](int i) { return i == 0 ? c->stream : c->tune_streams[i - 1]; };
+    if (ok) {
+        for (int i = 0; i < lanes; ++i) hipGraphLaunch(execs[i], stream_of(i));  // warm-up
+        for (int i = 1; i < lanes; ++i) hipStreamSynchronize(stream_of(i));
+        hipEventRecord(e0, c->stream);
+        for (int i = 1; i < lanes; ++i) hipStreamWaitEvent(stream_of(i), e0, 0);
+        for (int i = 0; i < lanes; ++i) hipGraphLaunch(execs[i], stream_of(i));
+        for (int i = 1; i < lanes; ++i) {
+            hipEventRecord(c->tune_events[i + 1], stream_of(i));
+            hipStreamWaitEvent(c->stream, c->tune_events[i + 1], 0);
+        }
+        hipEventRecord(e1, c->stream);
+        ok = hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess;
+    }
+    for (hipGraphExec_t e : execs) if (e) hipGraphExecDestroy(e);
+    if (graph) hipGraphDestroy(graph);
+    float ms = 1e30f;
+    if (!ok || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { failed = true; return 1e30f; }
+    return ms;
+}
+
 // Measures every applicable (kernel, tile, split-K) variant of one layer at batch n and remembers the fastest.
 int autotune_layer(demon_ctx *c, Layer *L, int n)
 {
@@ -1025,46 +1077,21 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
             }
         }
     }
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;
     float best = 1e30f;
     Layer::Tuned best_t{0, heur.tile, heur.ksplit};
     bool failed = false;
-    auto measure = [&](const Cand &cd) -> float {
+    for (size_t i = 0; i < cands.size() && !failed; ++i) {
+        const Cand &cd = cands[i];
         L->tuned[n] = Layer::Tuned{cd.kind, cd.tile, cd.ksplit};
-        // timed as a replayed hipGraph of five launches, like the real sequences run: the host-side planning of an eager
-        // launch (tens of microseconds for the small layers) must not leak into the comparison
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        if (ok) {
-            for (int i = 0; i < 5; ++i) run_layer(L, n, c->stream, c->d_ws);
-            ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        }
-        if (ok) {
-            hipGraphLaunch(exec, c->stream);  // warm-up
-            hipEventRecord(e0, c->stream);
-            hipGraphLaunch(exec, c->stream);
-            hipEventRecord(e1, c->stream);
-            ok = hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess;
-        }
-        if (exec) hipGraphExecDestroy(exec);
-        if (graph) hipGraphDestroy(graph);
-        if (!ok) { failed = true; return 1e30f; }
-        float ms = 0;
-        hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best) { best = ms; best_t = Layer::Tuned{cd.kind, cd.tile, cd.ksplit}; }
-        return ms;
-    };
-    for (size_t i = 0; i < cands.size() && !failed; ++i) measure(cands[i]);
-    if (failed) { hipEventDestroy(e0); hipEventDestroy(e1); return DEMON_ERR_HIP; }
+        const float ms = time_replay(c, [&] { run_layer(L, n, c->stream, c->d_ws); }, failed);
+        if (!failed && ms < best) { best = ms; best_t = Layer::Tuned{cd.kind, cd.tile, cd.ksplit}; }
+    }
+    if (failed) return DEMON_ERR_HIP;
     if (const char *pk = getenv("DEMON_TUNE_PICK")) {  // test hook: deterministic choice = candidate index
         const Cand &cd = cands[(size_t)atoi(pk) % cands.size()];
         best_t = Layer::Tuned{cd.kind, cd.tile, cd.ksplit};
     }
     L->tuned[n] = best_t;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     return DEMON_OK;
 }
 
@@ -1863,6 +1890,8 @@ int demon_destroy(demon_ctx *c)
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    for (hipStream_t st : c->tune_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+    for (hipEvent_t e : c->tune_events) hipEventDestroy(e);
     for (hipEvent_t e : c->events) if (e) hipEventDestroy(e);
     for (void *p : c->allocations) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -2140,6 +2169,11 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
     if (!strcmp(key, "reuse_image_features")) { c->opt_reuse_image = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "fused_pairs")) { c->opt_fused_pairs = value ? 1 : 0; return DEMON_OK; }
     if (!strcmp(key, "fused_inputs")) { c->opt_fused_inputs = value ? 1 : 0; return DEMON_OK; }
+    if (!strcmp(key, "tune_lanes")) {
+        if (value < 1 || value > 8) return fail(c, DEMON_ERR_INVALID, "tune_lanes must be in [1, 8]");
+        c->opt_tune_lanes = value;
+        return DEMON_OK;
+    }
     if (!strcmp(key, "side_branches")) { c->opt_side_branches = (value && c->side_stream && c->d_ws_side != c->d_ws) ? 1 : 0; return DEMON_OK; }
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }
@@ -2148,31 +2182,8 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
 // kind 6 / 7 when a chain is faster.
 int autotune_chain(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
 {
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;
     bool failed = false;
-    auto measure = [&](const std::function<void()> &body) -> float {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        if (ok) {
-            for (int i = 0; i < 5; ++i) body();
-            ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        }
-        if (ok) {
-            hipGraphLaunch(exec, c->stream);  // warm-up
-            hipEventRecord(e0, c->stream);
-            hipGraphLaunch(exec, c->stream);
-            hipEventRecord(e1, c->stream);
-            ok = hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess;
-        }
-        if (exec) hipGraphExecDestroy(exec);
-        if (graph) hipGraphDestroy(graph);
-        if (!ok) { failed = true; return 1e30f; }
-        float ms = 0;
-        hipEventElapsedTime(&ms, e0, e1);
-        return ms;
-    };
+    auto measure = [&](const std::function<void()> &body) -> float { return time_replay(c, body, failed); };
     float best = measure([&] { run_layer(Ly, n, c->stream, c->d_ws); run_layer(Lx, n, c->stream, c->d_ws); });
     Layer::Tuned best_t{-1, 0, 0};
     for (int kind : {6, 7})
@@ -2181,8 +2192,6 @@ int autotune_chain(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
             const float ms = measure([&] { run_chain(Ly, Lx, n, kind, v, c->stream, c->d_ws); });
             if (ms < best) { best = ms; best_t = Layer::Tuned{kind, v, 1}; }
         }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     if (failed) return DEMON_ERR_HIP;
     if (best_t.kind > 0) Ly->tuned[n] = best_t;
     return DEMON_OK;
@@ -2194,41 +2203,19 @@ int autotune_chain(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
 int autotune_fused_pair(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
 {
     if (!thin_applies(Ly) || !c->opt_fused_pairs) return DEMON_OK;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return DEMON_ERR_HIP;
     bool failed = false;
     auto measure = [&](bool fused) -> float {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        bool ok = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        if (ok) {
-            for (int i = 0; i < 5; ++i) {
-                if (fused && run_pair(Ly, Lx, n, c->stream)) continue;
-                run_layer(Ly, n, c->stream, c->d_ws);
-                run_layer(Lx, n, c->stream, c->d_ws);
-            }
-            ok = hipStreamEndCapture(c->stream, &graph) == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
-        }
-        float ms = 1e30f;
-        if (ok) {
-            hipGraphLaunch(exec, c->stream);
-            hipEventRecord(e0, c->stream);
-            hipGraphLaunch(exec, c->stream);
-            hipEventRecord(e1, c->stream);
-            ok = hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
-        }
-        if (exec) hipGraphExecDestroy(exec);
-        if (graph) hipGraphDestroy(graph);
-        if (!ok) failed = true;
-        return ms;
+        return time_replay(c, [&] {
+            if (fused && run_pair(Ly, Lx, n, c->stream)) return;
+            run_layer(Ly, n, c->stream, c->d_ws);
+            run_layer(Lx, n, c->stream, c->d_ws);
+        }, failed);
     };
     const bool had = Ly->tuned.count(n) > 0;
     const Layer::Tuned before = had ? Ly->tuned[n] : Layer::Tuned{14, 0, 1};
     Ly->tuned[n] = Layer::Tuned{12, 0, 1};
     const float two = measure(false);
     const float one = measure(true);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
     if (failed) return DEMON_ERR_HIP;
     if (one <= two) {
         // the fused launch wins: the k x 1 layer gets back the entry it had, or -- when nothing else was measured for it -- the explicit

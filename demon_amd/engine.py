@@ -129,11 +129,13 @@ class DemonContext:
         for layer, (kind, tile, ks) in plan.items():
             self._check(self.lib.demon_plan_set(self.h, int(n), layer.encode(), int(kind), int(tile), int(ks)))
 
-    def load_tuned_plan(self, n, directory=None, nearest=True):
+    def load_tuned_plan(self, n, directory=None, nearest=True, lanes=1):
         """installs demon_amd/tuned/plan_<H>x<W>_n<n>.json; without a plan for exactly this batch the plan of the NEAREST tuned
         batch size of the same shape (by ratio) is used -- its kernel families and tiles transfer, and kernels clamp a split-K
         that does not fit -- instead of the untuned heuristics.  Returns the batch size of the plan installed (== n for an
-        exact hit), or 0 when none exists for this shape."""
+        exact hit), or 0 when none exists for this shape.  lanes > 1 (the context is one lane of a group, demon_amd/lanes.py):
+        a plan tuned in throughput mode (tools/tune.py --lanes: plan_..._n<N>_l<L>.json) is preferred when one exists for the
+        batch size."""
         import glob
         import json
         import os
@@ -146,6 +148,11 @@ class DemonContext:
             m = re.match(re.escape(stem) + r"(\d+)\.json$", os.path.basename(path))
             if m:
                 have[int(m.group(1))] = path
+        if lanes > 1:   # throughput-mode plans replace the latency plan of the same batch size
+            for path in sorted(glob.glob(os.path.join(directory, stem + "*_l*.json"))):
+                m = re.match(re.escape(stem) + r"(\d+)_l(\d+)\.json$", os.path.basename(path))
+                if m:
+                    have[int(m.group(1))] = path
         if not have or (int(n) not in have and not nearest):
             return 0
         src = int(n) if int(n) in have else min(have, key=lambda b: abs(np.log(b / float(n))))

@@ -92,7 +92,9 @@ int demon_set_weights_blob_device(demon_ctx *ctx, const void *device_blob, int64
  * they do not depend on (fork / join by events, captured into the same hipGraph) -- same kernels, same results;
  * "fused_pairs" 0/1 (default 1): the first k x 1 / 1 x k pair (conv1, 6 input channels, the largest intermediate) as one launch,
  * the intermediate staying in LDS (conv_pair.hip) -- same arithmetic, other summation order;
- * "fused_inputs" 0/1 (default 1): the extra-input assembly of the iterative blocks / the refinement input as one launch each */
+ * "fused_inputs" 0/1 (default 1): the extra-input assembly of the iterative blocks / the refinement input as one launch each;
+ * "tune_lanes" 1..8 (default 1): demon_autotune times every candidate as that many CONCURRENT replays on as many streams
+ * ("throughput mode") -- the right cost when several passes are in flight on the GPU (demon_amd/lanes.py) */
 int demon_set_option(demon_ctx *ctx, const char *key, int value);
 /* Times every applicable kernel variant (im2col / patch-staged, tile shape, split-K) of every layer at batch n on
  * this GPU and keeps the fastest per layer (~1 s; results do not change, only launch plans). */

@@ -1,0 +1,77 @@
+"""bench.py as the driver launches it: the JSON line is the LAST thing on stdout and the only JSON line, also under
+`python -m torch.distributed.run` with the RCCL route forced on a single rank (the same code path every rank of an 8-GPU run
+takes: process group on nccl = RCCL, communicator through the C ABI, one ncclBroadcast of the packed weight slab)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _json_lines(stdout):
+    out = []
+    for line in stdout.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                out.append(json.loads(line))
+            except ValueError:
+                pass
+    return out
+
+
+def _env(**extra):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra)
+    return env
+
+
+def test_bench_under_torch_distributed_run_with_the_rccl_route():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline", "--no-e2e"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(DEMON_FORCE_DIST="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    recs = _json_lines(r.stdout)
+    assert len(recs) == 1, r.stdout[-2000:]
+    assert json.loads(lines[-1]) == recs[0]                       # the JSON line is the last thing the job prints
+    rec = recs[0]
+    assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["unit"] == "pairs/s" and rec["scaling"] == "weak"
+    assert rec["config"]["rccl_nranks"] == 1 and rec["config"]["weights_broadcast_route"] == "rccl"
+    assert rec["outputs_finite"] is True and rec["value"] > 100
+    assert abs(rec["value"] - 32 * 2 / (rec["ms_per_step"] * 2e-3)) < 1e-6 * rec["value"]
+
+
+def test_bench_default_line_has_roofline_and_host_to_host_rates():
+    """the line the driver records (cpu_baseline left out here: it is 30 s of host work and has its own protocol)"""
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT, env=_env(),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    recs = _json_lines(r.stdout)
+    assert len(recs) == 1
+    rec = recs[0]
+    assert "configs[2]" in rec["config"]["workload"] and rec["dtype"] == "f32" and rec["vs_baseline"] is None
+    for key in ("roofline", "roofline_worst", "roofline_family"):
+        e = rec[key]
+        assert e["bound"] == "mfma" and e["peak"] == 157.3 and e["unit"] == "TFLOP/s"
+        assert abs(e["frac"] - e["achieved"] / e["peak"]) < 1e-9
+        assert 0.0 < e["frac"] <= 1.0, (key, e["frac"])                                  # executed multiply-adds: a roofline fraction
+        assert e["algorithmic_frac"] >= e["frac"] - 1e-12
+        assert abs(e["frac"] - e["algorithmic_frac"] * e["mfma_flops_executed_per_algorithmic"]) < 1e-9
+    assert 0.0 < rec["pipeline_mfma_executed_frac"] <= rec["pipeline_mfma_frac"] <= 1.0
+    assert abs(rec["pipeline_mfma_frac"] - rec["value"] * 30.353e9 / 157.3e12) < 1e-9
+    assert 1 <= rec["config"]["lanes"] <= 5 and rec["config"]["steps_in_flight_per_gpu"] == rec["config"]["lanes"]
+    one = rec["single_lane"]
+    assert one["lane0_outputs_equal"] is True and 0.5 * rec["value"] < one["pairs_per_s"] < 1.02 * rec["value"]
+    x = rec["extra"]
+    assert x["end_to_end_pairs_per_s"] > 0
+    p = x["pipelined"]
+    assert p["pinned"] is True and p["outputs_equal_resident_run"] is True and 2 <= p["contexts"] <= 5
+    assert p["pairs_per_s"] > x["end_to_end_pairs_per_s"]                                  # overlap beats synchronous pageable copies
+    assert 0.5 < p["frac_of_resident"] < 1.5      # (two batches in flight hide per-launch latencies: the pipelined rate may exceed the one-stream rate)

@@ -38,11 +38,11 @@ def _reference_examples():
     return None
 
 
-def _stage(tmp, ref_examples, weights):
+def _stage(tmp, ref_examples, weights, script="example.py", checkpoint="demon_original"):
     from demon_amd import tf_checkpoint as ck
     ex = os.path.join(tmp, "examples")
     os.makedirs(ex)
-    os.symlink(os.path.join(ref_examples, "example.py"), os.path.join(ex, "example.py"))
+    os.symlink(os.path.join(ref_examples, script), os.path.join(ex, script))
     g = np.load(os.path.join(ROOT, "tests", "golden", "sculpture_inputs.npz"))
     for i in (1, 2):
         src = os.path.join(ref_examples, "sculpture%d.png" % i)
@@ -54,17 +54,17 @@ def _stage(tmp, ref_examples, weights):
             Image.fromarray(g["image%d_u8" % i]).save(dst)
     os.symlink(os.path.join(ROOT, "python"), os.path.join(tmp, "python"))
     os.makedirs(os.path.join(tmp, "weights"))
-    ck.save_tf_checkpoint(os.path.join(tmp, "weights", "demon_original"), weights)
-    return os.path.join(ex, "example.py")
+    ck.save_tf_checkpoint(os.path.join(tmp, "weights", checkpoint), weights)
+    return os.path.join(ex, script)
 
 
-def _run(script, dump):
+def _run(script, dump, args=()):
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "python", "tf_stub"), ROOT])
     env["MPLBACKEND"] = "Agg"
     env["DEMON_EVAL_DUMP"] = dump
     env.pop("DEMON_SYNTHETIC_WEIGHTS", None)
-    return subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(script))
+    return subprocess.run([sys.executable, script] + list(args), capture_output=True, text=True, timeout=900, env=env, cwd=os.path.dirname(script))
 
 
 @pytest.mark.gpu
@@ -115,3 +115,62 @@ def test_unmodified_reference_example_reaches_the_gpu_boundary_on_cpu(tmp_path, 
     assert "bootstrap_net = BootstrapNet(session, data_format)" in tail, tail
     assert "demon_create failed" in tail and "no HIP device" in tail, tail
     assert not os.path.exists(str(tmp_path / "result.npz"))     # nothing was evaluated
+
+
+# ---- the literal v2 driver, examples/example_v2.py:50-105 (needs --checkpoint; exits with "requires a GPU" without one) ----------
+
+def _reference_v2():
+    ref = _reference_examples()
+    return ref if ref and os.path.isfile(os.path.join(ref, "example_v2.py")) else None
+
+
+@pytest.mark.gpu
+def test_unmodified_reference_example_v2_runs_and_equals_demon_full():
+    from demon_amd import weights as W
+    import tempfile
+    ref = _reference_v2()
+    if ref is None:
+        pytest.skip("the reference's examples/example_v2.py is not on this machine ($DEMON_REFERENCE)")
+    w2 = W.synthetic_weights(seed=1, version=2)
+    with tempfile.TemporaryDirectory() as tmp:
+        script = _stage(tmp, ref, w2, script="example_v2.py", checkpoint="demon_v2")
+        with open(script) as f:
+            assert "from depthmotionnet.v2.networks import *" in f.read()
+        dump = os.path.join(tmp, "result.npz")
+        r = _run(script, dump, ["--checkpoint", os.path.join(tmp, "weights", "demon_v2")])
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        res = dict(np.load(dump))
+    assert int(res["BootstrapNet.calls"]) == 1 and int(res["IterativeNet.calls"]) == 3 and int(res["RefinementNet.calls"]) == 1
+    from demon_amd import DemonContext
+    ctx = DemonContext(0, 1, 192, 256, version=2)
+    try:
+        ctx.set_weights(w2)
+        ctx.load_tuned_plan(1)
+        want = ctx.full(res["BootstrapNet.image_pair"], res["BootstrapNet.image2_2"], iterations=3)
+    finally:
+        ctx.close()
+    np.testing.assert_array_equal(res["RefinementNet.predict_depth0"], want["predict_depth0"])
+    np.testing.assert_array_equal(res["RefinementNet.predict_normal0"], want["predict_normal0"])
+    np.testing.assert_array_equal(res["IterativeNet.predict_rotation"], want["predict_rotation"])
+    np.testing.assert_array_equal(res["IterativeNet.predict_translation"], want["predict_translation"])
+    np.testing.assert_array_equal(res["IterativeNet.predict_depth2"], want["predict_depth2"])
+
+
+def test_unmodified_reference_example_v2_stops_without_a_gpu():
+    """examples/example_v2.py:50-54: without a GPU the script prints 'Running this example requires a GPU' and exits 1 -- the
+    stand-in's tf.test.is_gpu_available answers through libdemon_hip.so, so that is what happens here (no CPU fallback)."""
+    import tempfile
+    import torch
+    from demon_amd import weights as W
+    ref = _reference_v2()
+    if ref is None:
+        pytest.skip("the reference's examples/example_v2.py is not on this machine ($DEMON_REFERENCE)")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the gpu test")
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "examples"))
+        os.symlink(os.path.join(ref, "example_v2.py"), os.path.join(tmp, "examples", "example_v2.py"))
+        os.symlink(os.path.join(ROOT, "python"), os.path.join(tmp, "python"))
+        r = _run(os.path.join(tmp, "examples", "example_v2.py"), os.path.join(tmp, "result.npz"), ["--checkpoint", os.path.join(tmp, "nothing")])
+        assert r.returncode == 1 and "Running this example requires a GPU" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+        assert not os.path.exists(os.path.join(tmp, "result.npz"))
