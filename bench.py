@@ -277,7 +277,8 @@ def main():
     elapsed_single = elapsed if args.lanes == 1 else timed(
         lambda k: [ctx.run_bootstrap(n) if boot_only else ctx.run_full(n, args.iterations) for _ in range(k)], ctx.synchronize)
     out1 = ctx.download_outputs(n, with_depth0=not boot_only)
-    lanes_equal_single = all(np.array_equal(out[k], out1[k]) for k in out)
+    # (bit-identical when both runs used the same launch plan; a throughput-mode plan sums in another order)
+    lanes_vs_single = max(float(np.abs(out[k].astype(np.float64) - out1[k]).sum() / max(np.abs(out1[k]).sum(), 1e-30)) for k in out)
 
     result = None
     if rank == 0:
@@ -301,7 +302,7 @@ def main():
                        "launch_plan": plan_src, "plan_setup_s": round(t_tune, 2)},
             "outputs_finite": bool(finite),
             "single_lane": {"pairs_per_s": pairs / elapsed_single, "ms_per_step": 1e3 * elapsed_single / args.steps,
-                            "lane0_outputs_equal": bool(lanes_equal_single),
+                            "lane0_outputs_rel_l1": lanes_vs_single, "lane0_outputs_match": bool(lanes_vs_single <= 1e-4),
                             "note": "the same K steps one at a time on one lane (side branches of the pass on a second stream, as in rounds 1-3)"},
         }
         if gflop_pair:

@@ -1647,6 +1647,19 @@ void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t 
         if (st.image_only == 3 && mode != 1) continue;
         if (pair_step_skipped(c, st, n)) continue;
         if ((st.fused == 1 && !c->opt_fused_inputs) || (st.fused == 2 && c->opt_fused_inputs)) continue;
+        // diagnostic hook (tools/ablate_lanes.py): DEMON_SKIP_STEPS="sub1,sub2" leaves out the steps whose name contains one of the
+        // substrings -- WRONG results, used only to read off what a group of layers costs while several passes are in flight
+        static const std::string skip = getenv("DEMON_SKIP_STEPS") ? getenv("DEMON_SKIP_STEPS") : "";
+        if (!skip.empty()) {
+            bool drop = false;
+            for (size_t b = 0; b < skip.size() && !drop;) {
+                size_t e = skip.find(',', b);
+                if (e == std::string::npos) e = skip.size();
+                drop = e > b && st.name.find(skip.substr(b, e - b)) != std::string::npos;
+                b = e + 1;
+            }
+            if (drop) continue;
+        }
         if (!branches) { st.fn(n, s); continue; }
         if (st.fork) {
             if (stream_wait(c, s, c->side_stream, ev)) side_open = true;

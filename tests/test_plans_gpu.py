@@ -73,7 +73,8 @@ def test_shipped_plan_matches_oracle(path):
     ctx = DemonContext(0, n, H, W, version=version)
     try:
         ctx.set_weights(w)
-        assert ctx.load_tuned_plan(n, nearest=False) == n
+        # plans tuned in throughput mode (tools/tune.py --lanes L -> ..._l<L>.json) are what a lane of a group loads
+        assert ctx.load_tuned_plan(n, nearest=False, lanes=meta.get("tune_lanes", 1)) == n
         assert ctx.get_plan(n) == {k: list(v) for k, v in meta["plan"].items()}
         pair, img2_2 = make_inputs(n, H, W, seed=100 + n)
         got = ctx.full(pair, img2_2, iterations=3)
