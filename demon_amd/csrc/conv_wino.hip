@@ -755,8 +755,11 @@ int wino1d_nuv(int kind) { return kind == 0 ? 4 : 5 + 2 * kind; }
 struct W1Shape { int wm, wn, tn, kg; };
 // 8..10: 48 / 96 tiles per workgroup -- the maps of this net are 3 * 2^k rows high (6 x 8, 12 x 16, 24 x 32 ...), so whole images fit
 // a 48- or 96-tile workgroup exactly where the 64-tile shapes leave a quarter of their tile slots empty (6 x 8: 24 tiles per image)
+// 11..12: ONE 16-channel block per workgroup, four waves along the tiles -- for layers with at most 16 output channels (the 64 -> 16
+// conv of the refinement net's depth head at full resolution, blocks_original.py:505-511): no MFMA rows spent on channels that do not
+// exist.  The input transform then has a single consumer, which only such layers have to accept.
 static const W1Shape kW1Shapes[WINO1D_VARIANTS] = {{2, 2, 2, 1}, {4, 1, 4, 1}, {2, 2, 4, 1}, {4, 2, 4, 1}, {2, 2, 2, 2}, {4, 1, 4, 2}, {2, 2, 4, 2}, {4, 2, 4, 2},
-                                                   {4, 1, 3, 4}, {2, 2, 3, 2}, {4, 2, 3, 4}};
+                                                   {4, 1, 3, 4}, {2, 2, 3, 2}, {4, 2, 3, 4}, {1, 4, 4, 1}, {1, 4, 2, 2}};
 int wino1d_variant_kg(int v) { return kW1Shapes[v].kg; }
 int wino1d_variant_bm(int v) { return 16 * kW1Shapes[v].wm; }
 int wino1d_variant_ntile(int v) { return 16 * kW1Shapes[v].tn * kW1Shapes[v].wn; }
@@ -781,6 +784,7 @@ bool wino1d_variant_ok(int kind, int v)
 bool wino1d_plan_geometry(Wino1Args &a, int kind, int variant, int axis, int n)
 {
     if (!wino1d_variant_ok(kind, variant) || a.Mpad % wino1d_variant_bm(variant)) return false;
+    if (wino1d_variant_bm(variant) == 16 && a.Cout > 16) return false;   // (one channel block per workgroup: see kW1Shapes)
     if (kind == 1 && axis == 1 && kW1Shapes[variant].tn == 3) return false;   // (register budget: 16-byte window vectors x 3 units x 2 sets)
     if (axis == 1) {   // filters along x load their windows as 8-byte (stride 1) / 16-byte (stride 2) vectors
         const int taps = kind == 0 ? 3 : 3 + 2 * kind;
@@ -815,7 +819,7 @@ bool wino1d_plan_geometry(Wino1Args &a, int kind, int variant, int axis, int n)
 
 long wino1d_workgroups(const Wino1Args &a, int variant)
 {
-    return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * (a.Mpad / wino1d_variant_bm(variant));
+    return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * ((a.Cout + wino1d_variant_bm(variant) - 1) / wino1d_variant_bm(variant));
 }
 
 void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, int cross, hipStream_t s)
@@ -863,14 +867,17 @@ static bool launch_w1_variant(const Wino1Args &a, int variant, dim3 grid, size_t
         case 7: return launch_w1<KIND, AXIS, 4, 2, 4, 2>(a, grid, lds, s);
         case 8: return launch_w1<KIND, AXIS, 4, 1, 3, 4>(a, grid, lds, s);
         case 9: return launch_w1<KIND, AXIS, 2, 2, 3, 2>(a, grid, lds, s);
-        default: return launch_w1<KIND, AXIS, 4, 2, 3, 4>(a, grid, lds, s);
+        case 10: return launch_w1<KIND, AXIS, 4, 2, 3, 4>(a, grid, lds, s);
+        case 11: return launch_w1<KIND, AXIS, 1, 4, 4, 1>(a, grid, lds, s);
+        default: return launch_w1<KIND, AXIS, 1, 4, 2, 2>(a, grid, lds, s);
     }
 }
 
 bool launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream)
 {
     const int groups = (a.N + a.G - 1) / a.G;
-    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / wino1d_variant_bm(variant)), (unsigned)a.ksplit);
+    const int bm = wino1d_variant_bm(variant);
+    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)((a.Cout + bm - 1) / bm), (unsigned)a.ksplit);   // (blocks of padding channels only would store nothing)
     const size_t lds = wino1d_lds_bytes(kind, variant);
 #define W1_KIND(KK)                                                              \
     case KK:                                                                     \

@@ -281,7 +281,7 @@ struct Wino1Args {
     unsigned m_tytx, m_tx, m_tilesx, m_tilesy;
     unsigned long long *tl;   // timeline records (diagnostic build), else null
 };
-constexpr int WINO1D_VARIANTS = 11;   // workgroup shapes (waves along Cout x waves along tiles x tile blocks per wave x K groups per step)
+constexpr int WINO1D_VARIANTS = 13;   // workgroup shapes (waves along Cout x waves along tiles x tile blocks per wave x K groups per step)
 int wino1d_variant_kg(int v);
 int wino1d_kind(int taps, int stride);   // -1: no minimal-filtering form built for this filter
 int wino1d_nuv(int kind);

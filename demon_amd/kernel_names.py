@@ -60,7 +60,7 @@ def kernel_tag(name):
     if m:   # (the 3 x 3 layers, tag "t3x3", run the 3-tap instance: the template name cannot tell them apart)
         kind, axis, wm, wn, tn, kg = map(int, m.groups())
         shapes = {(2, 2, 2): 0, (4, 1, 4): 1, (2, 2, 4): 2, (4, 2, 4): 3}
-        wide = {(4, 1, 3, 4): 8, (2, 2, 3, 2): 9, (4, 2, 3, 4): 10}   # 48 / 96 tiles per workgroup
+        wide = {(4, 1, 3, 4): 8, (2, 2, 3, 2): 9, (4, 2, 3, 4): 10, (1, 4, 4, 1): 11, (1, 4, 2, 2): 12}   # 48 / 96 tiles per workgroup; one 16-channel block
         v = wide[(wm, wn, tn, kg)] if (wm, wn, tn, kg) in wide else shapes.get((wm, wn, tn), -1) + 4 * (kg - 1)
         return "wino1d<t%d,v%d>" % (3 if kind == 0 else 3 + 2 * kind, v)
     m = re.search(r"conv_row_kernel<(\d+), ", name)

@@ -53,7 +53,7 @@ def test_all_variants_agree(gpu_ctx, layer):
     plans += [(4, v, ks) for v in range(18) for ks in (1, 2, 3, 5)]   # register-streaming kernel (applies when Cin % 16 == 0)
     plans += [(5, v, ks) for v in range(22) for ks in (1, 2, 3, 5)]    # fragment-tiled kernel (same requirement)
     plans += [(8, v, ks) for v in range(4) for ks in (1, 2, 3)]   # minimal-filtering transposed conv (conv_wino.hip; Cin >= 16)
-    plans += [(10, v, ks) for v in range(11) for ks in (1, 2)]     # 1-D minimal filtering (3 taps stride 1; 5 / 7 / 9 taps stride 2)
+    plans += [(10, v, ks) for v in range(13) for ks in (1, 2)]     # 1-D minimal filtering (3 taps stride 1; 5 / 7 / 9 taps stride 2)
     try:
         for plan in plans:
             os.environ["DEMON_FORCE_PLAN"] = "%d,%d,%d" % plan
@@ -160,7 +160,7 @@ def test_minimal_filtering_deconv(gpu_ctx, shape):
 WINO1D_LAYERS = [(64, 64, 3, 1, 1, 1, 24, 32), (128, 128, 1, 3, 1, 1, 12, 16), (64, 128, 5, 1, 2, 1, 48, 64), (128, 128, 1, 5, 1, 2, 24, 64),
                  (32, 64, 7, 1, 2, 1, 24, 32), (32, 32, 1, 7, 1, 2, 12, 64), (32, 32, 1, 9, 1, 2, 12, 64), (16, 32, 9, 1, 2, 1, 48, 64),
                  (18, 40, 3, 1, 1, 1, 7, 9), (30, 24, 1, 5, 1, 2, 5, 23), (20, 36, 7, 1, 2, 1, 17, 33), (256, 256, 3, 1, 1, 1, 12, 16), (34, 32, 1, 9, 1, 2, 9, 31), (34, 32, 1, 9, 1, 2, 9, 36), (30, 24, 1, 5, 1, 2, 5, 24), (32, 32, 1, 7, 1, 2, 6, 20),
-                 (130, 24, 3, 3, 1, 1, 48, 64), (64, 16, 3, 3, 1, 1, 40, 72), (64, 64, 3, 3, 1, 1, 24, 32), (18, 40, 3, 3, 1, 1, 7, 9)]   # 3 x 3: three 1 x 3 filters
+                 (130, 24, 3, 3, 1, 1, 48, 64), (64, 16, 3, 3, 1, 1, 40, 72), (32, 16, 3, 1, 1, 1, 24, 32), (22, 8, 1, 3, 1, 1, 12, 16), (16, 12, 1, 5, 1, 2, 12, 32), (64, 64, 3, 3, 1, 1, 24, 32), (18, 40, 3, 3, 1, 1, 7, 9)]   # 3 x 3: three 1 x 3 filters
 
 
 @pytest.mark.parametrize("layer", WINO1D_LAYERS)
@@ -179,7 +179,7 @@ def test_minimal_filtering_1d(gpu_ctx, layer):
     want = _ref("conv", x, w, b, (sh, sw))
     ran = 0
     try:
-        for v in range(11):
+        for v in range(13):
             for ks in (1, 2, 3):
                 os.environ["DEMON_FORCE_PLAN"] = "10,%d,%d" % (v, ks)
                 got = gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)

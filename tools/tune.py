@@ -31,7 +31,7 @@ for n in args.batch:
     if args.lanes > 1:
         ctx.set_option("tune_lanes", args.lanes)
     if args.only:
-        assert ctx.load_tuned_plan(n, nearest=False) == n, "no shipped plan to start from"
+        assert ctx.load_tuned_plan(n, nearest=False, lanes=args.lanes) == n, "no shipped plan to start from"
         os.environ["DEMON_TUNE_ONLY"] = args.only
     votes = collections.defaultdict(collections.Counter)
     for _ in range(args.rounds):
