@@ -1,0 +1,309 @@
+// conv_wino3.hip -- 3 x 3 stride-1 convolutions (the 24-channel heads, blocks_original.py:23-51, :238-294; the refinement net's conv1_1 /
+// conv2_1 and the 64 -> 16 conv of its depth head, :484-511) as three 1 x 3 minimal-filtering row filters with the TRANSFORMED INPUT ROWS
+// KEPT STATIONARY.
+//
+// conv_wino.hip's wino1d kernel runs such a layer as three passes over the channels, one per kernel row ky: every pass stages the
+// input row y + ky - 1 of its tiles, transforms it (F(2,3) along x: 4 values from a window of 4 pixels) and multiplies it by U[ky].  An
+// input row is therefore loaded, transformed and written to LDS three times -- once for each of the output rows y - 1, y, y + 1 it
+// contributes to -- and every MFMA needs a B operand of its own from LDS.  Here a wave owns TN CONSECUTIVE output rows of 16 tiles
+// (32 pixels) each: per K-step it reads the TN + 2 transformed input rows of its columns once and feeds each of them to up to three
+// MFMAs (one per ky, into the accumulators of three different output rows):
+//       acc[row r][e] += U[ky][e] (A operand) x T[input row r + ky - 1][e] (B operand),   ky = 0, 1, 2
+//   staging (loads, transform VALU, LDS writes) per MFMA: (TN + 2) / (3 TN) of the three-pass form   (TN = 4: one half)
+//   LDS operand reads per MFMA: (TN + 2 + 3) / (3 TN) instead of (TN + 1) / TN                       (TN = 4: 0.75 instead of 1.25)
+// which is what a layer with few output channels needs (a transformed input has few consumers there: one 16-channel block for the
+// depth head, two for the 24-channel heads) -- fp32 MFMAs share the SIMD's issue time with the vector ALU (conv_wino.hip).
+// Same transformed weights as the wino1d kernel (U[ky][e][ci][co], wino1d_repack_kernel with cross = 3), same arithmetic per
+// output up to the order in which the three rows' products are added (ky is now the inner index of a K-step, not the outer one).
+#include "internal.h"
+#include "wino1d_tables.h"
+
+namespace demon {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ int w3div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
+}
+
+// WM x WN waves: WM 16-channel blocks x WN blocks of 16 tile columns; TN output rows per wave; KG K groups (of 4 channels) per barrier
+template <int WM, int WN, int TN, int KG, bool MASK>
+__global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a)   // (2 waves per SIMD: 256 registers; 3 spills)
+{
+    using K = Wino1D<0>;
+    constexpr int NUV = K::NUV, NT = 64 * WM * WN, CKS = 4 * KG;
+    constexpr int BM = 16 * WM, TCOLS = 16 * WN, RIN = TN + 2;
+    constexpr int SLOTS = RIN * TCOLS;                         // (input row, tile column) slots per (e, channel)
+    constexpr int TP = SLOTS + ((SLOTS & 31) ? 0 : 16);        // pitch: the k = 0 / 1 halves of a 32-lane LDS access on different banks
+    constexpr int NUNIT = SLOTS * CKS;                         // staging units (channel, slot) per K-step
+    constexpr int UNITS = (NUNIT + NT - 1) / NT;
+    constexpr int NE = 3 * NUV;                                // (ky, e) weight planes
+    constexpr int ASZ = NE * CKS * BM, TSZ = NUV * CKS * TP;
+    constexpr int A4 = NE * BM * KG;                           // 16-byte chunks of the weight tile
+    constexpr int APER = (A4 + NT - 1) / NT;
+    constexpr int OOB = 0x7ffffff0, NREC = 0x40000000;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // As[2][ASZ], Ts[2][TSZ], one dummy 16-byte slot per thread
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l15 = lane & 15, lk = lane >> 4;
+    unsigned bx, by;
+    xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    const int m0 = by * BM;
+    const int t1 = w3div((int)bx, a.m_colsx);
+    const int cb = (int)bx - t1 * a.cols_x;           // column block
+    const int n = w3div(t1, a.m_rowsy);
+    const int rb = t1 - n * a.rows_y;                  // row block
+    const int r0 = rb * TN, c0 = cb * TCOLS;           // first output row / first tile column
+    const float *__restrict__ in0 = a.in + (long)n * a.in_n_stride;
+    const int HW = a.H * a.W;
+
+    // ---- staging units: unit i of this thread = (channel k of the K-step, input row j, tile column t); the window of tile column
+    // c = c0 + t lies inside the three 8-byte vectors [2 (c - 1), 2 (c + 2)) of row r0 - 1 + j
+    int goff[UNITS][3], tw[2][UNITS];
+    unsigned lastmask = 0;
+    const int last_c0 = (a.csteps - 1) * CKS;
+#pragma unroll
+    for (int i = 0; i < UNITS; ++i) {
+        const int w = tid + i * NT;
+        const bool uv = NUNIT % NT == 0 || w < NUNIT;
+        const int k = uv ? w / SLOTS : 0, slot = uv ? w - k * SLOTS : 0;
+        const int j = slot / TCOLS, t = slot - j * TCOLS;
+        const int gy = r0 - 1 + j, c = c0 + t;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int gx = 2 * (c - 1 + e);
+            const bool ok = uv & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
+            goff[i][e] = ok ? 4 * (k * HW + gy * a.W + gx) : OOB;
+        }
+        tw[0][i] = uv ? 2 * ASZ + k * TP + slot : 2 * ASZ + 2 * TSZ + tid * 4;   // (units past the end write their four values to the thread's dummy slot)
+        tw[1][i] = uv ? tw[0][i] + TSZ : tw[0][i];
+        asm volatile("" : "+v"(tw[1][i]));
+        lastmask |= ((last_c0 + k < a.Cin) ? 1u : 0u) << i;
+    }
+    // ---- weight loader: chunk f of the [ky * NUV + e][channel block][k][16] tile <-> U[ky][e][c0 + k][m0 + 16 blk + 4 c4 ..]
+    int aoff[APER], aw[2][APER];
+#pragma unroll
+    for (int i = 0; i < APER; ++i) {
+        const int f = tid + i * NT;
+        const bool fv = A4 % NT == 0 || f < A4;
+        const int c4 = f & 3, k = (f >> 2) % CKS, blk = (f / (4 * CKS)) % WM, e = f / (4 * CKS * WM);
+        aoff[i] = fv ? 4 * (int)(((long)e * a.Cin4 + k) * a.Mpad + m0 + blk * 16 + c4 * 4) : OOB;
+        aw[0][i] = fv ? f * 4 : 2 * ASZ + 2 * TSZ + tid * 4;
+        aw[1][i] = fv ? f * 4 + ASZ : 2 * ASZ + 2 * TSZ + tid * 4;
+    }
+    int ra[2], rt[2];
+    ra[0] = wm * (16 * CKS) + lane;
+    ra[1] = ra[0] + ASZ;
+    rt[0] = 2 * ASZ + lk * TP + wn * 16 + l15;
+    rt[1] = rt[0] + TSZ;
+    asm volatile("" : "+v"(ra[1]));
+    asm volatile("" : "+v"(rt[1]));
+
+    floatx4 acc[TN][NUV];
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+        for (int e = 0; e < NUV; ++e) acc[tb][e] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float pregA[UNITS][6], pregB[UNITS][6];
+    floatx4 aregA[APER], aregB[APER];
+    auto load_tiles = [&](float (&preg)[UNITS][6], floatx4 (&areg)[APER], int cs) {
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, NREC, 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)cs * CKS * a.Mpad), 0, NREC, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prsrc, goff[i][e], 0, 0));
+                preg[i][2 * e] = v[0];
+                preg[i][2 * e + 1] = v[1];
+            }
+#pragma unroll
+        for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
+    };
+    auto transform_store = [&](const float (&preg)[UNITS][6], const floatx4 (&areg)[APER], int buf, int cs) {
+        const bool last = MASK && cs == a.csteps - 1;   // (uniform) channels past Cin become zeros
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            float d[4], t[NUV];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = preg[i][1 + e];   // window starts one pixel left of the tile: x = 2 c - 1
+            K::input(d, t);
+            if constexpr (MASK) {
+                if (last) {
+                    const bool dead = !((lastmask >> i) & 1u);
+#pragma unroll
+                    for (int e = 0; e < NUV; ++e) t[e] = dead ? 0.0f : t[e];
+                }
+            }
+            float *T = smem + tw[buf][i];
+            if constexpr (NUNIT % NT == 0) {
+#pragma unroll
+                for (int e = 0; e < NUV; ++e) T[e * CKS * TP] = t[e];
+            } else {
+                const int st = (tid + i * NT < NUNIT) ? CKS * TP : 1;
+#pragma unroll
+                for (int e = 0; e < NUV; ++e) T[e * st] = t[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < APER; ++i) *reinterpret_cast<floatx4 *>(smem + aw[buf][i]) = areg[i];
+    };
+    // one item = one (K group, e): 3 weight fragments (ky) + RIN transformed input rows -> 3 TN MFMAs; the LDS reads of item g + 1 are
+    // issued before the MFMAs of item g (see conv_wino.hip: with few waves per SIMD the matrix pipe otherwise idles for an LDS latency)
+    constexpr int NI = KG * NUV;
+    auto compute = [&](int buf) {
+        const float *A = smem + ra[buf];
+        const float *T = smem + rt[buf];
+        float af[2][3], tf[2][RIN];
+        auto fetch = [&](int it, int set) {
+            const int kg = it / NUV, e = it - kg * NUV;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) af[set][ky] = A[(ky * NUV + e) * (WM * 16 * CKS) + kg * 64];
+#pragma unroll
+            for (int j = 0; j < RIN; ++j) tf[set][j] = T[(e * CKS + kg * 4) * TP + j * TCOLS];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            if (it + 1 < NI) fetch(it + 1, (it + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0x16);
+            const int e = it % NUV;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int tb = 0; tb < TN; ++tb)
+                    acc[tb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[it & 1][ky], tf[it & 1][tb + ky], acc[tb][e], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x16);
+        }
+    };
+
+    const int nsteps = a.csteps;
+    auto phys = [&](int x) { return min(x, nsteps - 1); };   // a run-ahead past the end re-reads the last step
+    load_tiles(pregA, aregA, phys(0));
+    load_tiles(pregB, aregB, phys(1));
+    transform_store(pregA, aregA, 0, phys(0));
+    __syncthreads();
+    {
+        int s = 0;
+        for (; s + 2 < nsteps; s += 2) {
+            load_tiles(pregA, aregA, phys(s + 2));
+            compute(0);
+            transform_store(pregB, aregB, 1, phys(s + 1));
+            __syncthreads();
+            load_tiles(pregB, aregB, phys(s + 3));
+            compute(1);
+            transform_store(pregA, aregA, 0, phys(s + 2));
+            __syncthreads();
+        }
+        if (s + 1 < nsteps) {
+            compute(0);
+            transform_store(pregB, aregB, 1, phys(s + 1));
+            __syncthreads();
+            compute(1);
+        } else {
+            compute(0);
+        }
+    }
+
+    // ---- epilogue: the two outputs of a tile from its NUV accumulators; lane = tile column, registers = 4 consecutive channels
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n * a.out_n_stride + (long)m0 * a.out_plane, 0, NREC, 0x00020000);
+    const int plane4 = 4 * (int)a.out_plane;
+    const int x0 = 2 * (c0 + wn * 16 + l15);
+#pragma unroll
+    for (int tb = 0; tb < TN; ++tb) {
+        const int y = r0 + tb;
+        const bool tv = y < a.H && x0 < a.W;
+        const int toff = tv ? 4 * (y * a.W + x0) + (wm * 16 + 4 * lk) * plane4 : OOB;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            const int col = wm * 16 + 4 * lk + e4;
+            float m[NUV], o0, o1;
+#pragma unroll
+            for (int e = 0; e < NUV; ++e) m[e] = acc[tb][e][e4];
+            K::output(m, o0, o1);
+            const float b = a.bias[m0 + col];   // (bias is padded to Mpad)
+            float v0 = o0 + b, v1 = o1 + b;
+            if (a.act) { v0 = fmaxf(v0, 0.1f * v0); v1 = fmaxf(v1, 0.1f * v1); }
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v0, v1}), orsrc, (tv && m0 + col < a.Cout) ? toff + e4 * plane4 : OOB, 0, 0);
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+struct W3Shape { int wm, wn, tn, kg; };
+static const W3Shape kW3Shapes[WINO3_VARIANTS] = {{2, 2, 4, 1}, {2, 4, 4, 1}, {4, 1, 4, 1}, {4, 2, 4, 1}, {1, 4, 4, 1}, {1, 4, 2, 2}, {2, 2, 2, 2}, {4, 1, 2, 2}};
+int wino3_variant_bm(int v) { return 16 * kW3Shapes[v].wm; }
+int wino3_variant_kg(int v) { return kW3Shapes[v].kg; }
+int wino3_variant_rows(int v) { return kW3Shapes[v].tn; }
+int wino3_variant_cols(int v) { return 16 * kW3Shapes[v].wn; }   // tile columns (2 pixels each) per workgroup
+
+static size_t wino3_lds_bytes(int v)
+{
+    const W3Shape s = kW3Shapes[v];
+    const int cks = 4 * s.kg, slots = (s.tn + 2) * 16 * s.wn, tp = slots + ((slots & 31) ? 0 : 16);
+    return sizeof(float) * (2ul * (12 * cks * 16 * s.wm + 4 * cks * tp) + 4ul * 64 * s.wm * s.wn);
+}
+
+bool wino3_plan_geometry(Wino3Args &a, int variant)
+{
+    if (variant < 0 || variant >= WINO3_VARIANTS) return false;
+    const W3Shape s = kW3Shapes[variant];
+    if ((a.W & 1) || a.Mpad % (16 * s.wm)) return false;               // rows are read as 8-byte vectors
+    if (s.wm == 1 && a.Cout > 16) return false;                        // (one channel block per workgroup is for <= 16 channels)
+    if (16 * s.wm > 16 && a.Cout <= 16) return false;
+    if (a.W < 32 * s.wn && a.W < 32) return false;                     // narrower maps stay on the wino1d kernel (its tiles span images)
+    a.rows_y = (a.H + s.tn - 1) / s.tn;
+    a.cols_x = (a.W / 2 + 16 * s.wn - 1) / (16 * s.wn);
+    if ((double)a.rows_y * s.tn * a.cols_x * 32 * s.wn > 2.5 * a.H * a.W) return false;   // mostly empty tile slots: not worth measuring
+    a.csteps = (a.Cin + 4 * s.kg - 1) / (4 * s.kg);
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    a.m_colsx = magic(a.cols_x);
+    a.m_rowsy = magic(a.rows_y);
+    return wino3_lds_bytes(variant) <= 160 * 1024;
+}
+
+long wino3_workgroups(const Wino3Args &a, int variant)
+{
+    return (long)a.N * a.rows_y * a.cols_x * ((a.Cout + wino3_variant_bm(variant) - 1) / wino3_variant_bm(variant));
+}
+
+template <int WM, int WN, int TN, int KG, bool MASK>
+static bool launch_w3m(const Wino3Args &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    static PerDeviceOnce once;
+    if (lds > 48 * 1024 &&
+        !once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3_rows_kernel<WM, WN, TN, KG, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
+        return false;
+    hipLaunchKernelGGL((wino3_rows_kernel<WM, WN, TN, KG, MASK>), grid, dim3(64 * WM * WN), lds, s, a);
+    return true;
+}
+
+template <int WM, int WN, int TN, int KG>
+static bool launch_w3(const Wino3Args &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    if (a.Cin % (4 * KG)) return launch_w3m<WM, WN, TN, KG, true>(a, grid, lds, s);
+    return launch_w3m<WM, WN, TN, KG, false>(a, grid, lds, s);
+}
+
+bool launch_wino3(const Wino3Args &a, int variant, hipStream_t stream)
+{
+    const int bm = wino3_variant_bm(variant);
+    dim3 grid((unsigned)(a.N * a.rows_y * a.cols_x), (unsigned)((a.Cout + bm - 1) / bm), 1);
+    const size_t lds = wino3_lds_bytes(variant);
+    switch (variant) {
+        case 0: return launch_w3<2, 2, 4, 1>(a, grid, lds, stream);
+        case 1: return launch_w3<2, 4, 4, 1>(a, grid, lds, stream);
+        case 2: return launch_w3<4, 1, 4, 1>(a, grid, lds, stream);
+        case 3: return launch_w3<4, 2, 4, 1>(a, grid, lds, stream);
+        case 4: return launch_w3<1, 4, 4, 1>(a, grid, lds, stream);
+        case 5: return launch_w3<1, 4, 2, 2>(a, grid, lds, stream);
+        case 6: return launch_w3<2, 2, 2, 2>(a, grid, lds, stream);
+        default: return launch_w3<4, 1, 2, 2>(a, grid, lds, stream);
+    }
+}
+
+}  // namespace demon

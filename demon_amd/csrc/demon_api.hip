@@ -733,6 +733,30 @@ bool run_wino1d(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipS
     return true;
 }
 
+// 3 x 3 stride-1 convs with the transformed input rows stationary (conv_wino3.hip), plan kind 15: variant = workgroup shape.  Uses the
+// transformed weights of the wino1d kernel (d_w1, cross = 3).
+bool wino3_applies(const Layer *L) { return L->d_w1 != nullptr && L->wino1d_kind_of() == 0 && L->wino1d_cross() == 3 && (L->in.W & 1) == 0; }
+
+bool fill_wino3_args(const Layer *L, const ConvArgs &a, int variant, Wino3Args &w)
+{
+    w.in = a.in; w.out = a.out; w.wu = L->d_w1; w.bias = a.bias;
+    w.N = a.N; w.Cin = L->Cin; w.Cin4 = L->Cin4(); w.H = a.H; w.W = a.W; w.in_n_stride = a.in_n_stride;
+    w.Cout = L->Cout; w.Mpad = L->Mpad; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
+    w.act = a.act; w.xcd = a.xcd;
+    return wino3_plan_geometry(w, variant);
+}
+
+bool run_wino3(const Layer *L, const ConvArgs &a, int variant, hipStream_t s)
+{
+    refresh_stream_weights(L, s);
+    Wino3Args w;
+    if (!wino3_applies(L) || !fill_wino3_args(L, a, variant, w)) return false;
+    if (!launch_wino3(w, variant, s)) return false;
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino3rows<t3x3,v%d>", variant);
+    g_last_kernel = g_kernel_tag;
+    return true;
+}
+
 // weight-streaming dense layer (dense_stream.hip), plan kind 11: ksplit = K slices across workgroups (dense_reduce_kernel adds them)
 bool dense_stream_applies(const Layer *L) { return L->d_wd != nullptr; }
 
@@ -831,6 +855,8 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 }
             } else if (kind == 10) {
                 if (wino1d_applies(L) && run_wino1d(L, a, tile, clamp_split(ks % 1000), s)) return;
+            } else if (kind == 15) {
+                if (run_wino3(L, a, tile, s)) return;
             } else if (kind == 13) {
                 if (row_applies(L) && run_row(L, a, s)) return;
             } else if (kind == 12) {
@@ -873,6 +899,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             if (t.kind == 10 && wino1d_applies(L) && run_wino1d(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 12 && thin_applies(L) && run_thin(L, a, s)) return;
             if (t.kind == 13 && row_applies(L) && run_row(L, a, s)) return;
+            if (t.kind == 15 && run_wino3(L, a, t.tile, s)) return;
             if (t.kind == 11 && dense_stream_applies(L) && run_dense_stream(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
@@ -1050,6 +1077,12 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
                 if (wgs * ks < 64) continue;
                 cands.push_back({10, v, ks});
             }
+        }
+    }
+    if (wino3_applies(L)) {
+        for (int v = 0; v < WINO3_VARIANTS; ++v) {
+            Wino3Args w;
+            if (fill_wino3_args(L, a, v, w) && wino3_workgroups(w, v) >= 128) cands.push_back({15, v, 1});
         }
     }
     if (thin_applies(L)) cands.push_back({12, 0, 1});
@@ -2290,8 +2323,9 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
     // 12 = the blocks' first layer with the weights in registers (conv_thin.hip; tile 0); its pair then runs as two launches
     // 13 = 1 x 7 / 1 x 9 stride-2 conv with <= 32 channels, whole reduction out of LDS (conv_row.hip; tile 0)
     // 14 = marker on the k x 1 layer of a conv_pair.hip pair: the fused launch was measured faster at this batch size (the layer alone: heuristics)
-    if (kind < 0 || kind > 14 || kind == 2 || kind == 9 || tile < 0 ||
-        tile >= (kind >= 12 ? 1 : kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
+    // 15 = 3 x 3 stride-1 conv, transformed input rows stationary (conv_wino3.hip; tile = workgroup shape)
+    if (kind < 0 || kind > 15 || kind == 2 || kind == 9 || tile < 0 ||
+        tile >= (kind == 15 ? (int)WINO3_VARIANTS : kind >= 12 ? 1 : kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     if (kind != 1 && ksplit >= 1000)   // (until round 3 "+ 1000" on kinds 0 / 4 / 5 selected a split-K form that no longer exists)
         return fail(c, DEMON_ERR_INVALID, "ksplit >= 1000 is only meaningful for the patch-staged kernel (pixel-tile shape)");
@@ -2301,6 +2335,7 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             if (kind == 8 && !wino_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the minimal-filtering kernel applies to transposed convs only");
             if (kind == 10 && !wino1d_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "no 1-D minimal-filtering form for this layer");
+            if (kind == 15 && !wino3_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_wino3.hip applies to 3 x 3 stride-1 convs with >= 16 input channels and rows of even length only");
             if (kind == 13 && !row_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_row.hip applies to 1 x 7 / 1 x 9 stride-2 convs with at most 32 channels on both sides only");
             if (kind == 12 && !thin_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_thin.hip applies to the 9 x 1 stride-2 first layer (Cin <= 6, Cout <= 32) only");
             if (kind == 11 && !dense_stream_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the weight-streaming kernel applies to dense layers only");

@@ -292,6 +292,30 @@ long wino1d_workgroups(const Wino1Args &a, int variant);
 void launch_wino1d_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, int cross, hipStream_t s);
 bool launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStream_t stream);   // false: nothing was launched
 
+// ---- 3 x 3 stride-1 convs as three 1 x 3 minimal-filtering row filters, transformed input rows stationary (conv_wino3.hip) -----------
+struct Wino3Args {
+    const float *in;
+    float *out;
+    const float *wu;     // transformed weights U[ky][e][Cin4][Mpad] (wino1d_repack_kernel, cross = 3)
+    const float *bias;
+    int N, Cin, Cin4, H, W;              // stride 1, one zero in front of every row / column: the output has the input's size
+    long in_n_stride;
+    int Cout, Mpad;
+    long out_n_stride, out_plane;
+    int act, csteps;                     // K-steps of 4 KG input channels
+    int rows_y, cols_x;                  // workgroup tiles per image: blocks of TN rows x blocks of 16 WN tile columns (a tile = 2 pixels of a row)
+    int xcd;
+    unsigned m_colsx, m_rowsy;
+};
+constexpr int WINO3_VARIANTS = 8;    // (waves along Cout x waves along columns x rows per wave x K groups per step)
+int wino3_variant_bm(int v);
+int wino3_variant_kg(int v);
+int wino3_variant_rows(int v);
+int wino3_variant_cols(int v);
+bool wino3_plan_geometry(Wino3Args &a, int variant);
+long wino3_workgroups(const Wino3Args &a, int variant);
+bool launch_wino3(const Wino3Args &a, int variant, hipStream_t stream);   // false: nothing was launched
+
 // ---- weight-streaming dense layer at small batch (dense_stream.hip): dense5 (v2), motion_fc1 -----------------------------------------------
 struct DenseArgs {
     const float *x;      // activations [N][x_n_stride], K consecutive floats per sample

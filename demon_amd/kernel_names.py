@@ -63,6 +63,10 @@ def kernel_tag(name):
         wide = {(4, 1, 3, 4): 8, (2, 2, 3, 2): 9, (4, 2, 3, 4): 10, (1, 4, 4, 1): 11, (1, 4, 2, 2): 12}   # 48 / 96 tiles per workgroup; one 16-channel block
         v = wide[(wm, wn, tn, kg)] if (wm, wn, tn, kg) in wide else shapes.get((wm, wn, tn), -1) + 4 * (kg - 1)
         return "wino1d<t%d,v%d>" % (3 if kind == 0 else 3 + 2 * kind, v)
+    m = re.search(r"wino3_rows_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        shapes3 = {(2, 2, 4, 1): 0, (2, 4, 4, 1): 1, (4, 1, 4, 1): 2, (4, 2, 4, 1): 3, (1, 4, 4, 1): 4, (1, 4, 2, 2): 5, (2, 2, 2, 2): 6, (4, 1, 2, 2): 7}
+        return "wino3rows<t3x3,v%d>" % shapes3.get(tuple(map(int, m.groups())), -1)
     m = re.search(r"conv_row_kernel<(\d+), ", name)
     if m:
         return "conv_row<32x128,t%d>" % (3 + 2 * int(m.group(1)))
@@ -91,6 +95,8 @@ def rocprof_kernel_name(tag):
         return "demon::conv_patch_kernel<%s, ...> (%sx%s tile, %s taps)" % (dims[0], dims[0], dims[1], rest.rstrip(">").split(",t")[-1])
     if fam == "wino_deconv" and len(dims) == 2:
         return "demon::wino_deconv_kernel<%d, ...> (16 channels x %s tiles per workgroup)" % (int(dims[1]) // 16, dims[1])
+    if fam == "wino3rows":
+        return "demon::wino3_rows_kernel<...> (%s)" % rest.rstrip(">")
     if fam == "wino1d":
         return "demon::wino1d_kernel<...> (%s)" % rest.rstrip(">")
     if fam == "deconv4":

@@ -111,6 +111,8 @@ int demon_autotune(demon_ctx *ctx, int n);
  *        3 small-Cout VALU kernel, 4 register-streaming kernel (conv_stream.hip), 5 fragment-tiled kernel (conv_frag.hip),
  *        6 / 7 on the k x 1 layer of a stride-1 pair: the pair runs as ONE chained launch of conv_frag / conv_stream variant `tile`;
  *        14 marker on the k x 1 layer of a conv_pair.hip pair: the fused launch measured faster at this batch size;
+ *        15 3 x 3 stride-1 conv as three 1 x 3 minimal-filtering row filters with the transformed input rows stationary
+ *           (conv_wino3.hip; tile = workgroup shape 0..7);
  *   tile = tile / variant id of that kernel; ksplit = K slices across workgroups, combined by a conv_splitk_reduce launch.
  *   demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
 int demon_num_layers(const demon_ctx *ctx);

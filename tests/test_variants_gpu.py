@@ -287,3 +287,37 @@ def test_row_conv_out_of_lds(gpu_ctx, layer):
         np.testing.assert_array_equal(np.where(lin >= 0, lin, np.float32(0.1) * lin), got)
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+# (cin, cout, H, W)
+WINO3_LAYERS = [(128, 24, 48, 64), (64, 16, 40, 72), (64, 64, 24, 64), (130, 24, 17, 34), (18, 40, 7, 66), (32, 16, 192, 256), (20, 64, 13, 128), (16, 8, 6, 64)]
+
+
+@pytest.mark.parametrize("layer", WINO3_LAYERS)
+def test_minimal_filtering_3x3_rows_stationary(gpu_ctx, layer):
+    """conv_wino3.hip: 3 x 3 stride-1 convs as three 1 x 3 F(2,3) row filters with the transformed input rows kept in LDS for the
+    three output rows they feed (plan kind 15).  Same products as the wino1d kernel's three-pass form, other order of addition: 1e-5
+    relative L1 against PyTorch for every workgroup shape that fits the layer; ragged heights / widths, Cin not a multiple of 4 / 8,
+    Cout below a channel block; deterministic."""
+    cin, cout, H, W = layer
+    rng = np.random.default_rng(35)
+    n = 3
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("conv", x, w, b, (1, 1))
+    ran = 0
+    try:
+        for v in range(8):
+            os.environ["DEMON_FORCE_PLAN"] = "15,%d,1" % v
+            got = gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True)
+            tag = gpu_ctx.last_kernel()
+            if not tag.startswith("wino3rows<"):
+                continue   # the shape does not fit this layer (channel block vs Cout, too many empty tile slots)
+            ran += 1
+            err = rel_l1(got, want)
+            assert err < 1e-5, "variant %d (%s): rel L1 %.3e" % (v, tag, err)
+            np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True))
+        assert ran >= 1, layer
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
