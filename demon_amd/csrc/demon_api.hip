@@ -1688,7 +1688,13 @@ void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t 
             for (size_t b = 0; b < skip.size() && !drop;) {
                 size_t e = skip.find(',', b);
                 if (e == std::string::npos) e = skip.size();
-                drop = e > b && st.name.find(skip.substr(b, e - b)) != std::string::npos;
+                if (e > b) {
+                    std::string pat = skip.substr(b, e - b);
+                    const bool anchored = pat.back() == '$';   // "name$": the step name must END with it
+                    if (anchored) pat.pop_back();
+                    const size_t at = anchored ? (st.name.size() >= pat.size() ? st.name.rfind(pat) : std::string::npos) : st.name.find(pat);
+                    drop = at != std::string::npos && (!anchored || at + pat.size() == st.name.size());
+                }
                 b = e + 1;
             }
             if (drop) continue;

@@ -4,11 +4,14 @@
 usage: python tools/ablate_lanes.py [--lanes 3] [--batch 32]"""
 import argparse, os, subprocess, sys, json
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-GROUPS = [("none", ""), ("conv1", "/conv1y,/conv1x,/conv1"), ("conv2", "/conv2y,/conv2x"), ("conv2_1", "/conv2_1"), ("conv3", "/conv3y,/conv3x"), ("conv3_1", "/conv3_1"),
+GROUPS = [("none", ""), ("conv1y", "/conv1y"), ("conv1x", "/conv1x"), ("conv2", "/conv2y,/conv2x"), ("conv2_1", "/conv2_1"), ("conv3", "/conv3y,/conv3x"), ("conv3_1", "/conv3_1"),
           ("conv4", "/conv4y,/conv4x"), ("conv4_1", "/conv4_1"), ("conv5", "/conv5y,/conv5x"), ("conv5_1", "/conv5_1"),
           ("refine4", "refine4/upconv"), ("refine3", "refine3/upconv"), ("refine2", "refine2/upconv"),
-          ("heads2", "predict_flow2/conv,predict_depthnormal2/conv"), ("extra+motion+flow5", "conv2_extra,assemble,motion,predict_flow5,upsample_flow5"),
-          ("netRefine", "netRefine/")]
+          ("heads2 conv1", "predict_flow2/conv1,predict_depthnormal2/conv1"), ("heads2 conv2", "predict_flow2/conv2,predict_depthnormal2/conv2"),
+          ("extra inputs", "conv2_extra,assemble_inputs"), ("motion", "motion"), ("flow5 head", "predict_flow5,upsample_flow5"),
+          ("rf conv0+assemble", "netRefine/conv0,netRefine/assemble"), ("rf conv1", "netRefine/conv1$"), ("rf conv1_1", "netRefine/conv1_1"),
+          ("rf conv2", "netRefine/conv2$"), ("rf conv2_1", "netRefine/conv2_1"), ("rf refine1", "netRefine/refine1"), ("rf refine0", "netRefine/refine0"),
+          ("rf pd0 conv1", "predict_depth0/conv1"), ("rf pd0 conv2", "predict_depth0/conv2")]
 ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=3)
 ap.add_argument("--batch", type=int, default=32)
