@@ -159,6 +159,10 @@ def main():
                     help="N > 1: rccl = one ncclBroadcast of the packed weight slab through the C ABI (default); torch = "
                          "torch.distributed.broadcast of the TF-layout blob")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host (H2D + kernels + D2H) measurement")
+    ap.add_argument("--plan-lanes", type=int, default=0,
+                    help="which shipped launch plan to load: 1 = the plan tuned for one pass at a time, > 1 = the throughput-mode plan "
+                         "(tools/tune.py --lanes).  Default: what --lanes implies.  `--lanes 1 --plan-lanes 3` runs the headline's kernels one "
+                         "pass at a time (what the rocprofv3 / PMC passes of tools/collect_profiles.sh use: counters serialise kernels anyway)")
     ap.add_argument("--lanes", type=int, default=0,
                     help="contexts per GPU the steps go round (each with its own stream, arena, resident batch and hipGraph): that many "
                          "steps are in flight at a time.  Default 0 = measure 1 .. 5 lanes at start-up (untimed set-up) and keep the best; "
@@ -217,10 +221,11 @@ def main():
     if args.reuse_image_features:
         ctx.set_option("reuse_image_features", 1)
     plan_src = "heuristic"
+    plan_lanes = args.plan_lanes or args.lanes
     if not args.no_autotune:
         # per-layer kernel / tile / split-K selection (untimed set-up): the plan shipped in demon_amd/tuned/ for this
         # workload (measured once on an MI355X by tools/tune.py) or, when there is none, measured now
-        src_n = 0 if args.retune else ctx.load_tuned_plan(n, lanes=args.lanes)
+        src_n = 0 if args.retune else ctx.load_tuned_plan(n, lanes=plan_lanes)
         if src_n:
             plan_src = "demon_amd/tuned" if src_n == n else "demon_amd/tuned (plan of batch %d, nearest tuned size)" % src_n
         else:
@@ -271,12 +276,15 @@ def main():
     for c in group.ctxs[1:]:
         finite = finite and all(np.isfinite(v).all() for v in c.download_outputs(n, with_depth0=not boot_only).values())
     group.close()          # lane 0 = ctx stays (and gets its side branches back)
-    if args.lanes > 1 and not args.no_autotune and not args.retune:
+    shipped_plans = not args.no_autotune and not args.retune
+    if args.lanes > 1 and shipped_plans:
         ctx.load_tuned_plan(n)   # ... and the plan tuned for one pass at a time, when the lanes ran a throughput-mode plan
     # the same K steps one at a time on one lane (round 1-3's protocol), for comparison
     elapsed_single = elapsed if args.lanes == 1 else timed(
         lambda k: [ctx.run_bootstrap(n) if boot_only else ctx.run_full(n, args.iterations) for _ in range(k)], ctx.synchronize)
     out1 = ctx.download_outputs(n, with_depth0=not boot_only)
+    if args.lanes > 1 and shipped_plans:
+        ctx.load_tuned_plan(n, lanes=plan_lanes)   # the per-launch profile below is of the kernels the headline ran
     # (bit-identical when both runs used the same launch plan; a throughput-mode plan sums in another order)
     lanes_vs_single = max(float(np.abs(out[k].astype(np.float64) - out1[k]).sum() / max(np.abs(out1[k]).sum(), 1e-30)) for k in out)
 

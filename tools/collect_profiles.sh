@@ -13,8 +13,12 @@ for spec in "config1_bootstrap:--workload bootstrap" "batch1:--batch 1" "batch8:
   name=${spec%%:*}; args=${spec#*:}
   timeout 400 python bench.py $args --no-cpu-baseline > $out/bench_$name.json 2> $out/layers_$name.txt
 done
-B="python bench.py --no-cpu-baseline --no-e2e --no-roofline"
+# rocprofv3 passes: the headline's kernels (throughput-mode plan) ONE PASS AT A TIME -- counter collection serialises kernels anyway, and
+# the per-kernel durations of the trace are then comparable with bench.py's own per-launch hip-event times (which are taken one
+# launch after the other); stats_lanes = the default command (3 passes in flight: kernel durations overlap and stretch)
+B="python bench.py --no-cpu-baseline --no-e2e --no-roofline --lanes 1 --plan-lanes 3"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- $B > $out/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_lanes -o p -- python bench.py --no-cpu-baseline --no-e2e --no-roofline > $out/stats_lanes.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- $B > $out/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o p -- $B > $out/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma -o p -- $B > $out/pmc_mfma.log 2>&1
