@@ -454,31 +454,33 @@ def main():
             result["extra"] = {"end_to_end_pairs_per_s": n / dt, "end_to_end_ms_per_step": 1e3 * dt,
                                "h2d_bytes_per_step": in_b, "d2h_bytes_per_step": out_b,
                                "note": "demon_full from / to pageable numpy buffers on rank 0, synchronous copies (PCIe-inclusive; not the metric)"}
-            if args.workload in ("full", "v2"):
-                # the host-to-host rate a batch-streaming caller gets (examples/evaluation.py:225-256 fed in batches): two contexts /
-                # streams fed alternately from page-locked host arrays, the copies of one batch under the kernels of the other
-                # (demon_amd/pipeline.py); also never `value`
-                from demon_amd.pipeline import Pipeline
-                pipe = Pipeline(host_weights, batch=n, height=height, width=width, device=local_rank, version=version, contexts=5, calibrate=True)
-                try:
-                    hb = pipe.buffers(8 * n)
-                    try:
-                        for i in range(8):
-                            hb.image_pair[i * n:(i + 1) * n] = pair
-                            hb.image2_2[i * n:(i + 1) * n] = img2_2
-                        r = pipe.throughput(hb, args.iterations, repeats=2)
-                        same = all(np.array_equal(hb.out[k][:n], out[k]) for k in hb.out)
-                    finally:
-                        hb.release()
-                finally:
-                    pipe.close()
-                result["extra"]["pipelined"] = dict(r, outputs_equal_resident_run=bool(same), frac_of_resident=r["pairs_per_s"] / (value / world),
-                                                    lanes_calibration_pairs_per_s={str(k): round(v, 1) for k, v in (pipe.lane_rates or {}).items()},
-                                                    note="demon_amd.pipeline.Pipeline: lanes fed round robin from page-locked host arrays, "
-                                                         "asynchronous H2D / D2H under the other lanes' kernels; 8 batches per pass")
         if not args.no_cpu_baseline and world == 1 and args.workload == "full":
             result["cpu_baseline"] = cpu_baseline(host_weights)
     ctx.close()
+    if rank == 0 and not args.no_e2e and args.workload in ("full", "v2"):
+        # (after this rank's context is gone: the lanes of the pipeline then get the stream -> hardware-queue mapping of a process of
+        # their own, which is what a batch-streaming caller has)
+        # the host-to-host rate a batch-streaming caller gets (examples/evaluation.py:225-256 fed in batches): two contexts /
+        # streams fed alternately from page-locked host arrays, the copies of one batch under the kernels of the other
+        # (demon_amd/pipeline.py); also never `value`
+        from demon_amd.pipeline import Pipeline
+        pipe = Pipeline(host_weights, batch=n, height=height, width=width, device=local_rank, version=version, contexts=5, calibrate=True)
+        try:
+            hb = pipe.buffers(8 * n)
+            try:
+                for i in range(8):
+                    hb.image_pair[i * n:(i + 1) * n] = pair
+                    hb.image2_2[i * n:(i + 1) * n] = img2_2
+                r = pipe.throughput(hb, args.iterations, repeats=2)
+                same = all(np.array_equal(hb.out[k][:n], out[k]) for k in hb.out)
+            finally:
+                hb.release()
+        finally:
+            pipe.close()
+        result["extra"]["pipelined"] = dict(r, outputs_equal_resident_run=bool(same), frac_of_resident=r["pairs_per_s"] / (value / world),
+                                            lanes_calibration_pairs_per_s={str(k): round(v, 1) for k, v in (pipe.lane_rates or {}).items()},
+                                            note="demon_amd.pipeline.Pipeline: lanes fed round robin from page-locked host arrays, "
+                                                 "asynchronous H2D / D2H under the other lanes' kernels; 8 batches per pass")
     if distributed:
         flush_c_stdio()       # RCCL's version banner sits in the C stdio buffer when stdout is a pipe: out with it BEFORE the result,
         dist.barrier()        # on every rank, so that the JSON line is the last thing this job prints
