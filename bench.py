@@ -241,10 +241,10 @@ def main():
         c.upload_inputs(*make_inputs(args.batch, seed=1000 * li + rank, height=height, width=width))
     group.run_resident(n, len(group), args.iterations, boot_only)
     group.synchronize()
-    lane_rates = None
+    lane_rates, lane_mapping = None, None
     if auto_lanes:   # which lane count pays off depends on the runtime's stream -> hardware-queue mapping in THIS process: measured
         lane_rates = group.calibrate(n, args.iterations, boot_only)
-        args.lanes = len(group)
+        args.lanes, lane_mapping = len(group), group.mapping
     t_tune = time.perf_counter() - t0
 
     def barrier():
@@ -302,7 +302,8 @@ def main():
             "config": {"workload": wl_desc % ((args.batch,) if boot_only else (args.batch, args.iterations)),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "iterations": args.iterations,
                        "lanes": args.lanes, "steps_in_flight_per_gpu": args.lanes,
-                       "lanes_calibration_pairs_per_s": {str(k): round(v, 1) for k, v in lane_rates.items()} if lane_rates else None,
+                       "lanes_calibration_pairs_per_s": {str(k): round(v, 1) for k, v in lane_rates.items()} if lane_rates else None,   # "lanes@placeholder streams"
+                       "lanes_mapping": lane_mapping,
                        "sharding": "independent pairs per rank, no data-path collective",
                        "weights": "synthetic He-normal seed 1; %s, %.1f ms (untimed)" % (bcast_desc, 1e3 * t_bcast),
                        "weights_broadcast_ms": round(1e3 * t_bcast, 2), "weights_broadcast_route": bcast_route,

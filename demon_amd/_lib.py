@@ -67,6 +67,8 @@ SIGNATURES = {
     "demon_run_full": (_I, [_P, _I, _I]),
     "demon_run_bootstrap": (_I, [_P, _I]),
     "demon_synchronize": (_I, [_P]),
+    "demon_release_streams": (_I, [_P]),
+    "demon_acquire_streams": (_I, [_P]),
     "demon_download_outputs": (_I, [_P, _I, ctypes.POINTER(DemonOutputs), c_float_p]),
     "demon_download_normal0": (_I, [_P, _I, c_float_p]),
     "demon_upload_inputs_async": (_I, [_P, _I, c_float_p, c_float_p]),

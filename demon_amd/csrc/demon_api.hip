@@ -2428,6 +2428,31 @@ int demon_synchronize(demon_ctx *c)
     return DEMON_OK;
 }
 
+// The runtime binds a HIP stream to one of a few hardware queues when the stream is created, by a rule that depends on every stream
+// alive in the process; two busy streams on one queue serialise.  A lane group (demon_amd/lanes.py) that measures a poor mapping
+// gives its streams back (demon_release_streams on every lane), optionally creates a few placeholder streams, and takes new ones
+// (demon_acquire_streams, lane by lane).  Captured hipGraphs stay valid: a graph exec is not tied to the stream it was captured on.
+int demon_release_streams(demon_ctx *c)
+{
+    if (!c) return DEMON_ERR_INVALID;
+    hipSetDevice(c->device);
+    if (c->stream) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipStreamDestroy(c->stream)); c->stream = nullptr; }
+    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
+    return DEMON_OK;
+}
+
+int demon_acquire_streams(demon_ctx *c)
+{
+    if (!c) return DEMON_ERR_INVALID;
+    hipSetDevice(c->device);
+    if (!c->stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (!c->side_stream && c->variant != 0 && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) {
+        c->side_stream = nullptr;
+        c->opt_side_branches = 0;
+    }
+    return DEMON_OK;
+}
+
 int demon_download_outputs(demon_ctx *c, int n, const demon_outputs *o, float *depth0)
 {
     if (!c || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "bad batch");

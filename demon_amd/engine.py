@@ -240,6 +240,13 @@ class DemonContext:
     def synchronize(self):
         self._check(self.lib.demon_synchronize(self.h))
 
+    def release_streams(self):
+        """gives the context's HIP streams back (nothing may be in flight); acquire_streams() before the next use"""
+        self._check(self.lib.demon_release_streams(self.h))
+
+    def acquire_streams(self):
+        self._check(self.lib.demon_acquire_streams(self.h))
+
     def download_outputs(self, n, with_depth0=True):
         arrays, o = self._alloc_outputs(n)
         d0 = np.empty((n, 1, self.H, self.W), np.float32) if with_depth0 else None

@@ -140,6 +140,13 @@ int demon_upload_inputs(demon_ctx *ctx, int n, const float *image_pair, const fl
 int demon_run_full(demon_ctx *ctx, int n, int iterations);
 int demon_run_bootstrap(demon_ctx *ctx, int n);
 int demon_synchronize(demon_ctx *ctx);
+/* Stream <-> hardware-queue mapping: the HIP runtime binds a stream to one of a few hardware queues at creation, by a rule that
+ * depends on every stream alive in the process, and two busy streams on one queue serialise.  A group of contexts that measures a
+ * poor mapping (demon_amd/lanes.py: LaneGroup.calibrate) releases all its streams, optionally creates placeholder streams
+ * (demon_create_ops contexts), and acquires new ones context by context.  Nothing may be in flight; captured graphs stay valid.
+ * Between release and acquire the context must not be used.                                                              */
+int demon_release_streams(demon_ctx *ctx);
+int demon_acquire_streams(demon_ctx *ctx);
 int demon_download_outputs(demon_ctx *ctx, int n, const demon_outputs *out, float *predict_depth0);
 /* Pipelining across contexts (copy / compute overlap): the _async variants only enqueue on the context's stream; the host buffers
  * must be page-locked (demon_host_register pins an existing allocation, e.g. a numpy array) and stay untouched until

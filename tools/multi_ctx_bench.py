@@ -20,7 +20,8 @@ total = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 ks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 3, 4]
 w = W.synthetic_weights(seed=1)
 dummies = [DemonContext(0, 1) for _ in range(int(os.environ.get("DUMMY", "0")))]   # idle contexts: their streams occupy hardware queues
-print("idle contexts: %d" % len(dummies), flush=True)
+pads = [DemonContext.ops_only(0) for _ in range(int(os.environ.get("PAD1", "0")))]   # one-stream contexts: shift the lanes' streams by one
+print("idle contexts: %d, one-stream pads: %d" % (len(dummies), len(pads)), flush=True)
 for k in ks:
     n = total // k if mode == "split" else total
     ctxs = []
