@@ -2562,6 +2562,30 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
     for (auto &e : ev) HIP_TRY(c, hipEventCreate(&e));
     std::vector<double> ms(seq.size(), 0.0), red_ms(seq.size(), 0.0);
     std::vector<char> marked(seq.size(), 0);
+    if (c->opt_tune_lanes > 1) {
+        // throughput mode (option tune_lanes = L): what a launch costs while others run beside it -- L concurrent replays of a graph
+        // of 5 launches of the step, on L streams; a launch is charged 1 / (5 L) of the time until all are done
+        for (auto &e : ev) hipEventDestroy(e);
+        for (size_t i = 0; i < seq.size(); ++i) {
+            bool failed = false;
+            g_last_kernel = nullptr;
+            double t = 0;
+            for (int rep = 0; rep < repeats && !failed; ++rep) t += time_replay(c, [&] { seq[i]->fn(n, c->stream); }, failed);
+            if (failed) return fail(c, DEMON_ERR_HIP, "throughput-mode profile failed at step " + seq[i]->name);
+            tags[i] = g_last_kernel ? g_last_kernel : "";
+            ms[i] = t / (5.0 * c->opt_tune_lanes);
+        }
+        *count = (int)seq.size();
+        for (size_t i = 0; i < seq.size() && (int)i < cap; ++i) {
+            memset(&rec[i], 0, sizeof rec[i]);
+            strncpy(rec[i].name, seq[i]->name.c_str(), sizeof rec[i].name - 1);
+            strncpy(rec[i].kernel, !tags[i].empty() ? tags[i].c_str() : seq[i]->kernel.c_str(), sizeof rec[i].kernel - 1);
+            rec[i].flops = seq[i]->flops_per_sample * n;
+            rec[i].bytes = seq[i]->bytes_per_sample * n + seq[i]->bytes_fixed;
+            rec[i].ms = (float)(ms[i] / repeats);
+        }
+        return DEMON_OK;
+    }
     for (int rep = 0; rep < repeats + 1; ++rep) {  // first pass = warm-up
         for (size_t i = 0; i < seq.size(); ++i) {
             HIP_TRY(c, hipEventRecord(ev[3 * i], c->stream));

@@ -504,3 +504,39 @@ def test_chained_pairs_equal_the_two_launches(synth_weights):
             ctx.set_plan(n, {"netFlow1/conv2_1y": [6, 6, 1]})
     finally:
         ctx.close()
+
+
+def test_lane_group_calibration_keeps_results(synth_weights):
+    """demon_amd/lanes.py: several contexts on one GPU fed round robin.  Calibration measures lane counts and stream -> hardware-queue
+    mappings (demon_release_streams / demon_acquire_streams behind placeholder streams) and must not change a single bit of what
+    a lane computes; every lane equals a plain context with the same launch plan; lanes > 1 run without side branches."""
+    from demon_amd import DemonContext
+    from demon_amd.lanes import LaneGroup
+    n = 2
+    group = LaneGroup(synth_weights, lanes=3, batch=n)
+    try:
+        batches = [make_inputs(n, seed=40 + i) for i in range(3)]
+        group.upload_inputs(batches)
+        group.run_resident(n, 3, iterations=2)
+        group.synchronize()
+        before = [c.download_outputs(n) for c in group.ctxs]
+        rates = group.calibrate(n, iterations=2, steps_per_lane=2, pads=(0, 1, 2))
+        assert set(rates) >= {"1@0", "2@0", "3@0", "2@1", "3@2"} and all(v > 0 for v in rates.values())
+        assert group.mapping["lanes"] == len(group) and 1 <= len(group) <= 3 and group.mapping["placeholder_streams"] in (0, 1, 2)
+        group.run_resident(n, len(group), iterations=2)
+        group.synchronize()
+        for c, b in zip(group.ctxs, before):
+            after = c.download_outputs(n)
+            for k in after:
+                np.testing.assert_array_equal(after[k], b[k], err_msg=k)
+        single = DemonContext(0, n, 192, 256)
+        try:
+            single.set_weights(synth_weights)
+            single.set_plan(n, group.ctxs[0].get_plan(n))
+            want = single.full(*batches[0], iterations=2)
+        finally:
+            single.close()
+        for k in before[0]:
+            np.testing.assert_array_equal(before[0][k], want[k], err_msg=k)
+    finally:
+        group.close()
