@@ -344,6 +344,8 @@ def main():
                 import re
                 if tag.startswith("wino_deconv"):
                     return 9.0 / 16.0            # F(2,2) x F(2,2) per sub-pixel class
+                if tag.startswith("wino3rows<f4"):
+                    return 6.0 / 12.0            # F(4,3) row filters
                 m = re.match(r"(?:wino1d|wino3rows|conv_row<32x128,|wino1d_chain)<?t(\d+)", tag)
                 if m:
                     taps = int(m.group(1))

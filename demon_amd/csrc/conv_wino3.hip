@@ -13,8 +13,14 @@
 //   LDS operand reads per MFMA: (TN + 2 + 3) / (3 TN) instead of (TN + 1) / TN                       (TN = 4: 0.75 instead of 1.25)
 // which is what a layer with few output channels needs (a transformed input has few consumers there: one 16-channel block for the
 // depth head, two for the 24-channel heads) -- fp32 MFMAs share the SIMD's issue time with the vector ALU (conv_wino.hip).
-// Same transformed weights as the wino1d kernel (U[ky][e][ci][co], wino1d_repack_kernel with cross = 3), same arithmetic per
-// output up to the order in which the three rows' products are added (ky is now the inner index of a K-step, not the outer one).
+// F(2,3) form: same transformed weights as the wino1d kernel (U[ky][e][ci][co], wino1d_repack_kernel with cross = 3), same arithmetic
+// per output up to the order in which the three rows' products are added (ky is now the inner index of a K-step, not the outer one).
+// F(4,3) form (template parameter F4): FOUR consecutive outputs of a row per tile from a window of six pixels with 6 products per
+// kernel row instead of 12 (F(2,3): 8) -- 0.5 x the direct convolution's multiply-adds; interpolation points 0, +-1, +-2, infinity
+// (wino1d_tables.h, generated and checked in exact rationals; fp32 error 2 x a direct fp32 sum at K = 128, tools/gen_wino1d.py).
+// Its weights U43[ky][e][ci][co] (6 planes per kernel row) live in a buffer of their own (wino3_repack43_kernel).
+#include <type_traits>
+
 #include "internal.h"
 #include "wino1d_tables.h"
 
@@ -26,12 +32,20 @@ namespace {
 __device__ __forceinline__ int w3div(int n, unsigned magic) { return magic ? (int)__umulhi((unsigned)n, magic) : n; }
 }
 
-// WM x WN waves: WM 16-channel blocks x WN blocks of 16 tile columns; TN output rows per wave; KG K groups (of 4 channels) per barrier
-template <int WM, int WN, int TN, int KG, bool MASK>
-__global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a)   // (2 waves per SIMD: 256 registers; 3 spills)
+struct Rows23 {   // F(2,3) along x: the 3-tap stride-1 kind of wino1d_tables.h with the interface of Wino43
+    static constexpr int NUV = Wino1D<0>::NUV, WIN = Wino1D<0>::WIN, OUT = 2;
+    static __device__ __forceinline__ void input(const float (&d)[WIN], float (&t)[NUV]) { Wino1D<0>::input(d, t); }
+    static __device__ __forceinline__ void output(const float (&m)[NUV], float (&o)[OUT]) { Wino1D<0>::output(m, o[0], o[1]); }
+};
+
+// WM x WN waves: WM 16-channel blocks x WN blocks of 16 tile columns; TN output rows per wave; KG K groups (of 4 channels) per barrier;
+// F4: tiles of four pixels (F(4,3)) instead of two (F(2,3))
+template <int WM, int WN, int TN, int KG, bool MASK, bool F4>
+__global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a)   // (2 waves per SIMD: 256 registers; 3 spills -- the F(4,3) shapes therefore hold 2 or 3 rows per wave: 24 accumulator registers per row)
 {
-    using K = Wino1D<0>;
-    constexpr int NUV = K::NUV, NT = 64 * WM * WN, CKS = 4 * KG;
+    using K = typename std::conditional<F4, Wino43, Rows23>::type;
+    constexpr int NUV = K::NUV, WIN = K::WIN, OUT = K::OUT, NT = 64 * WM * WN, CKS = 4 * KG;
+    constexpr int PWD = F4 ? 6 : 6;   // floats a unit loads: F(2,3) three 8-byte vectors around its window, F(4,3) exactly its six pixels
     constexpr int BM = 16 * WM, TCOLS = 16 * WN, RIN = TN + 2;
     constexpr int SLOTS = RIN * TCOLS;                         // (input row, tile column) slots per (e, channel)
     constexpr int TP = SLOTS + ((SLOTS & 31) ? 0 : 16);        // pitch: the k = 0 / 1 halves of a 32-lane LDS access on different banks
@@ -58,8 +72,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     const float *__restrict__ in0 = a.in + (long)n * a.in_n_stride;
     const int HW = a.H * a.W;
 
-    // ---- staging units: unit i of this thread = (channel k of the K-step, input row j, tile column t); the window of tile column
-    // c = c0 + t lies inside the three 8-byte vectors [2 (c - 1), 2 (c + 2)) of row r0 - 1 + j
+    // ---- staging units: unit i of this thread = (channel k of the K-step, input row j, tile column t).  F(2,3): the window of tile
+    // column c = c0 + t (4 pixels from x = 2 c - 1) lies inside the three 8-byte vectors [2 (c - 1), 2 (c + 2)) of row r0 - 1 + j;
+    // F(4,3): the window is the pixel 4 c - 1, the 16-byte vector [4 c, 4 c + 4) and the pixel 4 c + 4
     int goff[UNITS][3], tw[2][UNITS];
     unsigned lastmask = 0;
     const int last_c0 = (a.csteps - 1) * CKS;
@@ -72,7 +87,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
         const int gy = r0 - 1 + j, c = c0 + t;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            const int gx = 2 * (c - 1 + e);
+            const int gx = F4 ? (e == 0 ? 4 * c - 1 : (e == 1 ? 4 * c : 4 * c + 4)) : 2 * (c - 1 + e);
             const bool ok = uv & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
             goff[i][e] = ok ? 4 * (k * HW + gy * a.W + gx) : OOB;
         }
@@ -107,29 +122,38 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
         for (int e = 0; e < NUV; ++e) acc[tb][e] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    float pregA[UNITS][6], pregB[UNITS][6];
+    float pregA[UNITS][PWD], pregB[UNITS][PWD];
     floatx4 aregA[APER], aregB[APER];
-    auto load_tiles = [&](float (&preg)[UNITS][6], floatx4 (&areg)[APER], int cs) {
+    auto load_tiles = [&](float (&preg)[UNITS][PWD], floatx4 (&areg)[APER], int cs) {
         const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, NREC, 0x00020000);
         const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)cs * CKS * a.Mpad), 0, NREC, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < UNITS; ++i)
+        for (int i = 0; i < UNITS; ++i) {
+            if constexpr (F4) {
+                preg[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][0], 0, 0));
+                const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, goff[i][1], 0, 0));
 #pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prsrc, goff[i][e], 0, 0));
-                preg[i][2 * e] = v[0];
-                preg[i][2 * e + 1] = v[1];
+                for (int j = 0; j < 4; ++j) preg[i][1 + j] = v[j];
+                preg[i][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][2], 0, 0));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prsrc, goff[i][e], 0, 0));
+                    preg[i][2 * e] = v[0];
+                    preg[i][2 * e + 1] = v[1];
+                }
             }
+        }
 #pragma unroll
         for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
     };
-    auto transform_store = [&](const float (&preg)[UNITS][6], const floatx4 (&areg)[APER], int buf, int cs) {
+    auto transform_store = [&](const float (&preg)[UNITS][PWD], const floatx4 (&areg)[APER], int buf, int cs) {
         const bool last = MASK && cs == a.csteps - 1;   // (uniform) channels past Cin become zeros
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
-            float d[4], t[NUV];
+            float d[WIN], t[NUV];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = preg[i][1 + e];   // window starts one pixel left of the tile: x = 2 c - 1
+            for (int e = 0; e < WIN; ++e) d[e] = preg[i][(F4 ? 0 : 1) + e];   // the window starts one pixel left of the tile
             K::input(d, t);
             if constexpr (MASK) {
                 if (last) {
@@ -211,7 +235,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     // ---- epilogue: the two outputs of a tile from its NUV accumulators; lane = tile column, registers = 4 consecutive channels
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n * a.out_n_stride + (long)m0 * a.out_plane, 0, NREC, 0x00020000);
     const int plane4 = 4 * (int)a.out_plane;
-    const int x0 = 2 * (c0 + wn * 16 + l15);
+    const int x0 = OUT * (c0 + wn * 16 + l15);
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
         const int y = r0 + tb;
@@ -220,45 +244,88 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
             const int col = wm * 16 + 4 * lk + e4;
-            float m[NUV], o0, o1;
+            float m[NUV], o[OUT];
 #pragma unroll
             for (int e = 0; e < NUV; ++e) m[e] = acc[tb][e][e4];
-            K::output(m, o0, o1);
+            K::output(m, o);
             const float b = a.bias[m0 + col];   // (bias is padded to Mpad)
-            float v0 = o0 + b, v1 = o1 + b;
-            if (a.act) { v0 = fmaxf(v0, 0.1f * v0); v1 = fmaxf(v1, 0.1f * v1); }
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{v0, v1}), orsrc, (tv && m0 + col < a.Cout) ? toff + e4 * plane4 : OOB, 0, 0);
+#pragma unroll
+            for (int j = 0; j < OUT; ++j) {
+                o[j] += b;
+                if (a.act) o[j] = fmaxf(o[j], 0.1f * o[j]);
+            }
+            const int off = (tv && m0 + col < a.Cout) ? toff + e4 * plane4 : OOB;
+            if constexpr (F4) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, floatx4{o[0], o[1], o[2], o[3]}), orsrc, off, 0, 0);
+            } else {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{o[0], o[1]}), orsrc, off, 0, 0);
+            }
         }
     }
 }
 
+// U43[ky][e][ci][co] = sum_t G43[e][t] wp[(ky*3 + t)*Cin + ci][co]; rows ci >= Cin stay zero (the buffer is zero-filled once)
+__global__ __launch_bounds__(256) void wino3_repack43_kernel(float *__restrict__ wu, const float *__restrict__ wp, int Cin, int Cin4, int Mpad)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)Cin * Mpad) return;
+    const int ci = (int)(idx / Mpad), co = (int)(idx - (long)ci * Mpad);
+    for (int ky = 0; ky < 3; ++ky) {
+        float w[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w[t] = wp[((long)(ky * 3 + t) * Cin + ci) * Mpad + co];
+#pragma unroll
+        for (int e = 0; e < Wino43::NUV; ++e) {
+            float u = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) u += Wino43::g(e, t) * w[t];
+            wu[(((long)ky * Wino43::NUV + e) * Cin4 + ci) * Mpad + co] = u;
+        }
+    }
+}
+
+void launch_wino3_repack43(float *wu, const float *wp, int Cin, int Cin4, int Mpad, hipStream_t s)
+{
+    const long total = (long)Cin * Mpad;
+    hipLaunchKernelGGL(wino3_repack43_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------
+// variants 0 .. 7: F(2,3) tiles of two pixels; 8 .. 15: the same workgroup shapes on F(4,3) tiles of four pixels
 struct W3Shape { int wm, wn, tn, kg; };
-static const W3Shape kW3Shapes[WINO3_VARIANTS] = {{2, 2, 4, 1}, {2, 4, 4, 1}, {4, 1, 4, 1}, {4, 2, 4, 1}, {1, 4, 4, 1}, {1, 4, 2, 2}, {2, 2, 2, 2}, {4, 1, 2, 2}};
-int wino3_variant_bm(int v) { return 16 * kW3Shapes[v].wm; }
-int wino3_variant_kg(int v) { return kW3Shapes[v].kg; }
-int wino3_variant_rows(int v) { return kW3Shapes[v].tn; }
-int wino3_variant_cols(int v) { return 16 * kW3Shapes[v].wn; }   // tile columns (2 pixels each) per workgroup
+constexpr int W3_SHAPES = 8;
+static_assert(WINO3_VARIANTS == 2 * W3_SHAPES, "eight workgroup shapes per form");
+static const W3Shape kW3Shapes[WINO3_VARIANTS] = {{2, 2, 4, 1}, {2, 4, 4, 1}, {4, 1, 4, 1}, {4, 2, 4, 1}, {1, 4, 4, 1}, {1, 4, 2, 2}, {2, 2, 2, 2}, {4, 1, 2, 2},
+                                                  {2, 2, 2, 2}, {4, 1, 2, 2}, {2, 2, 3, 1}, {4, 1, 3, 1}, {1, 4, 2, 1}, {1, 4, 3, 1}, {2, 1, 2, 2}, {4, 2, 3, 1}};
+static const W3Shape &w3shape(int v) { return kW3Shapes[v]; }
+bool wino3_variant_f4(int v) { return v >= W3_SHAPES; }
+int wino3_variant_bm(int v) { return 16 * w3shape(v).wm; }
+int wino3_variant_kg(int v) { return w3shape(v).kg; }
+int wino3_variant_rows(int v) { return w3shape(v).tn; }
+int wino3_variant_cols(int v) { return 16 * w3shape(v).wn; }   // tile columns (2 or 4 pixels each) per workgroup
 
 static size_t wino3_lds_bytes(int v)
 {
-    const W3Shape s = kW3Shapes[v];
+    const W3Shape s = w3shape(v);
+    const int nuv = wino3_variant_f4(v) ? 6 : 4;
     const int cks = 4 * s.kg, slots = (s.tn + 2) * 16 * s.wn, tp = slots + ((slots & 31) ? 0 : 16);
-    return sizeof(float) * (2ul * (12 * cks * 16 * s.wm + 4 * cks * tp) + 4ul * 64 * s.wm * s.wn);
+    return sizeof(float) * (2ul * (3 * nuv * cks * 16 * s.wm + nuv * cks * tp) + 4ul * 64 * s.wm * s.wn);
 }
 
 bool wino3_plan_geometry(Wino3Args &a, int variant)
 {
     if (variant < 0 || variant >= WINO3_VARIANTS) return false;
-    const W3Shape s = kW3Shapes[variant];
-    if ((a.W & 1) || a.Mpad % (16 * s.wm)) return false;               // rows are read as 8-byte vectors
+    const W3Shape s = w3shape(variant);
+    const int out = wino3_variant_f4(variant) ? 4 : 2;                 // pixels per tile
+    if (a.W % out || a.Mpad % (16 * s.wm)) return false;               // windows are read as 8- / 16-byte vectors
     if (s.wm == 1 && a.Cout > 16) return false;                        // (one channel block per workgroup is for <= 16 channels)
     if (16 * s.wm > 16 && a.Cout <= 16) return false;
-    if (a.W < 32 * s.wn && a.W < 32) return false;                     // narrower maps stay on the wino1d kernel (its tiles span images)
+    if (a.W < 32) return false;                                        // narrower maps stay on the wino1d kernel (its tiles span images)
     a.rows_y = (a.H + s.tn - 1) / s.tn;
-    a.cols_x = (a.W / 2 + 16 * s.wn - 1) / (16 * s.wn);
-    if ((double)a.rows_y * s.tn * a.cols_x * 32 * s.wn > 2.5 * a.H * a.W) return false;   // mostly empty tile slots: not worth measuring
+    a.cols_x = (a.W / out + 16 * s.wn - 1) / (16 * s.wn);
+    if ((double)a.rows_y * s.tn * a.cols_x * 16 * out * s.wn > 2.5 * a.H * a.W) return false;   // mostly empty tile slots: not worth measuring
     a.csteps = (a.Cin + 4 * s.kg - 1) / (4 * s.kg);
     auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
     a.m_colsx = magic(a.cols_x);
@@ -271,38 +338,47 @@ long wino3_workgroups(const Wino3Args &a, int variant)
     return (long)a.N * a.rows_y * a.cols_x * ((a.Cout + wino3_variant_bm(variant) - 1) / wino3_variant_bm(variant));
 }
 
-template <int WM, int WN, int TN, int KG, bool MASK>
+template <int WM, int WN, int TN, int KG, bool MASK, bool F4>
 static bool launch_w3m(const Wino3Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
     static PerDeviceOnce once;
     if (lds > 48 * 1024 &&
-        !once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3_rows_kernel<WM, WN, TN, KG, MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
+        !once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3_rows_kernel<WM, WN, TN, KG, MASK, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
         return false;
-    hipLaunchKernelGGL((wino3_rows_kernel<WM, WN, TN, KG, MASK>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((wino3_rows_kernel<WM, WN, TN, KG, MASK, F4>), grid, dim3(64 * WM * WN), lds, s, a);
     return true;
 }
 
-template <int WM, int WN, int TN, int KG>
+template <int WM, int WN, int TN, int KG, bool F4>
 static bool launch_w3(const Wino3Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    if (a.Cin % (4 * KG)) return launch_w3m<WM, WN, TN, KG, true>(a, grid, lds, s);
-    return launch_w3m<WM, WN, TN, KG, false>(a, grid, lds, s);
+    if (a.Cin % (4 * KG)) return launch_w3m<WM, WN, TN, KG, true, F4>(a, grid, lds, s);
+    return launch_w3m<WM, WN, TN, KG, false, F4>(a, grid, lds, s);
 }
 
+// a.wu: U[ky][e][Cin4][Mpad] with 4 planes per kernel row for variants 0 .. 7, U43 with 6 planes for variants 8 .. 15
 bool launch_wino3(const Wino3Args &a, int variant, hipStream_t stream)
 {
     const int bm = wino3_variant_bm(variant);
     dim3 grid((unsigned)(a.N * a.rows_y * a.cols_x), (unsigned)((a.Cout + bm - 1) / bm), 1);
     const size_t lds = wino3_lds_bytes(variant);
     switch (variant) {
-        case 0: return launch_w3<2, 2, 4, 1>(a, grid, lds, stream);
-        case 1: return launch_w3<2, 4, 4, 1>(a, grid, lds, stream);
-        case 2: return launch_w3<4, 1, 4, 1>(a, grid, lds, stream);
-        case 3: return launch_w3<4, 2, 4, 1>(a, grid, lds, stream);
-        case 4: return launch_w3<1, 4, 4, 1>(a, grid, lds, stream);
-        case 5: return launch_w3<1, 4, 2, 2>(a, grid, lds, stream);
-        case 6: return launch_w3<2, 2, 2, 2>(a, grid, lds, stream);
-        default: return launch_w3<4, 1, 2, 2>(a, grid, lds, stream);
+        case 0: return launch_w3<2, 2, 4, 1, false>(a, grid, lds, stream);
+        case 1: return launch_w3<2, 4, 4, 1, false>(a, grid, lds, stream);
+        case 2: return launch_w3<4, 1, 4, 1, false>(a, grid, lds, stream);
+        case 3: return launch_w3<4, 2, 4, 1, false>(a, grid, lds, stream);
+        case 4: return launch_w3<1, 4, 4, 1, false>(a, grid, lds, stream);
+        case 5: return launch_w3<1, 4, 2, 2, false>(a, grid, lds, stream);
+        case 6: return launch_w3<2, 2, 2, 2, false>(a, grid, lds, stream);
+        case 7: return launch_w3<4, 1, 2, 2, false>(a, grid, lds, stream);
+        case 8: return launch_w3<2, 2, 2, 2, true>(a, grid, lds, stream);
+        case 9: return launch_w3<4, 1, 2, 2, true>(a, grid, lds, stream);
+        case 10: return launch_w3<2, 2, 3, 1, true>(a, grid, lds, stream);
+        case 11: return launch_w3<4, 1, 3, 1, true>(a, grid, lds, stream);
+        case 12: return launch_w3<1, 4, 2, 1, true>(a, grid, lds, stream);
+        case 13: return launch_w3<1, 4, 3, 1, true>(a, grid, lds, stream);
+        case 14: return launch_w3<2, 1, 2, 2, true>(a, grid, lds, stream);
+        default: return launch_w3<4, 2, 3, 1, true>(a, grid, lds, stream);
     }
 }
 

@@ -62,6 +62,9 @@ struct Layer {
     // 1-D minimal filtering (conv_wino.hip): k x 1 / 1 x k layers with 3 taps stride 1 or 5 / 7 / 9 taps stride 2; U[e][Cin4][Mpad] in d_w1
     float *d_w1 = nullptr;
     mutable bool w1_dirty = true;
+    // F(4,3) weights of the 3 x 3 stride-1 layers for conv_wino3.hip: U43[ky][e][Cin4][Mpad], 6 planes per kernel row
+    float *d_w3 = nullptr;
+    mutable bool w3_dirty = true;
     // weight-streaming dense kernel (dense_stream.hip): the weights re-blocked to [Mpad / 128][Cin][128]
     float *d_wd = nullptr;
     mutable bool wd_dirty = true;
@@ -298,6 +301,12 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
         L->d_w1 = dev_alloc(c, sizeof(float) * nu);
         if (!L->d_w1 || hipMemset(L->d_w1, 0, sizeof(float) * nu) != hipSuccess) return false;
         L->w1_dirty = true;
+        if (L->wino1d_cross() == 3 && L->in.W % 4 == 0 && L->in.W >= 32) {
+            const size_t n3 = ((size_t)3 * 6 * L->Cin4() + 16) * L->Mpad;
+            L->d_w3 = dev_alloc(c, sizeof(float) * n3);
+            if (!L->d_w3 || hipMemset(L->d_w3, 0, sizeof(float) * n3) != hipSuccess) return false;
+            L->w3_dirty = true;
+        }
     }
     if (L->kind == Layer::DENSE && L->in.H * L->in.W == 1 && L->out.H * L->out.W == 1 && !L->scale && dense_stream_geometry_ok(L->Cin, L->Mpad, 1) &&
         (long)L->Cin * L->Mpad >= (1l << 20)) {   // >= 4 MB of weights: below that a dense layer is launch bound whatever streams them
@@ -367,6 +376,7 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
     L->have_kernel = true;
     L->wf_dirty = true;
     L->w1_dirty = true;
+    L->w3_dirty = true;
     L->wd_dirty = true;
     return DEMON_OK;
 }
@@ -606,6 +616,10 @@ void refresh_stream_weights(const Layer *L, hipStream_t s)
         launch_wino1d_repack(L->d_w1, L->d_wp, L->wino1d_kind_of(), L->Cin, L->Cin4(), L->Mpad, L->wino1d_cross(), s);
         L->w1_dirty = false;
     }
+    if (L->d_w3 && L->w3_dirty) {   // F(4,3) weights of conv_wino3.hip
+        launch_wino3_repack43(L->d_w3, L->d_wp, L->Cin, L->Cin4(), L->Mpad, s);
+        L->w3_dirty = false;
+    }
     if (L->d_wd && L->wd_dirty) {   // re-blocked weights of the weight-streaming dense kernel (dense_stream.hip)
         launch_dense_repack(L->d_wd, L->d_wp, L->Cin, L->Mpad, s);
         L->wd_dirty = false;
@@ -739,7 +753,10 @@ bool wino3_applies(const Layer *L) { return L->d_w1 != nullptr && L->wino1d_kind
 
 bool fill_wino3_args(const Layer *L, const ConvArgs &a, int variant, Wino3Args &w)
 {
-    w.in = a.in; w.out = a.out; w.wu = L->d_w1; w.bias = a.bias;
+    if (variant < 0 || variant >= WINO3_VARIANTS) return false;
+    const bool f4 = wino3_variant_f4(variant);
+    if (f4 && !L->d_w3) return false;
+    w.in = a.in; w.out = a.out; w.wu = f4 ? L->d_w3 : L->d_w1; w.bias = a.bias;
     w.N = a.N; w.Cin = L->Cin; w.Cin4 = L->Cin4(); w.H = a.H; w.W = a.W; w.in_n_stride = a.in_n_stride;
     w.Cout = L->Cout; w.Mpad = L->Mpad; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
     w.act = a.act; w.xcd = a.xcd;
@@ -752,7 +769,7 @@ bool run_wino3(const Layer *L, const ConvArgs &a, int variant, hipStream_t s)
     Wino3Args w;
     if (!wino3_applies(L) || !fill_wino3_args(L, a, variant, w)) return false;
     if (!launch_wino3(w, variant, s)) return false;
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino3rows<t3x3,v%d>", variant);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino3rows<%s,v%d>", wino3_variant_f4(variant) ? "f4t3x3" : "t3x3", variant);
     g_last_kernel = g_kernel_tag;
     return true;
 }
@@ -2136,7 +2153,7 @@ void slab_arrived(demon_ctx *c)
 {
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
-    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->w1_dirty = true; L->wd_dirty = true; }
+    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->w1_dirty = true; L->w3_dirty = true; L->wd_dirty = true; }
 }
 }  // namespace
 extern "C" {

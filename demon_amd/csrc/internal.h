@@ -296,7 +296,7 @@ bool launch_wino1d(const Wino1Args &a, int kind, int variant, int axis, hipStrea
 struct Wino3Args {
     const float *in;
     float *out;
-    const float *wu;     // transformed weights U[ky][e][Cin4][Mpad] (wino1d_repack_kernel, cross = 3)
+    const float *wu;     // transformed weights U[ky][e][Cin4][Mpad]: F(2,3) 4 planes per kernel row (wino1d_repack_kernel, cross = 3), F(4,3) 6 planes
     const float *bias;
     int N, Cin, Cin4, H, W;              // stride 1, one zero in front of every row / column: the output has the input's size
     long in_n_stride;
@@ -307,8 +307,10 @@ struct Wino3Args {
     int xcd;
     unsigned m_colsx, m_rowsy;
 };
-constexpr int WINO3_VARIANTS = 8;    // (waves along Cout x waves along columns x rows per wave x K groups per step)
+constexpr int WINO3_VARIANTS = 16;   // 8 workgroup shapes (waves along Cout x waves along columns x rows per wave x K groups per step) x {F(2,3), F(4,3)}
 int wino3_variant_bm(int v);
+bool wino3_variant_f4(int v);   // F(4,3) tiles of four pixels (own transformed weights: launch_wino3_repack43)
+void launch_wino3_repack43(float *wu, const float *wp, int Cin, int Cin4, int Mpad, hipStream_t s);
 int wino3_variant_kg(int v);
 int wino3_variant_rows(int v);
 int wino3_variant_cols(int v);

@@ -290,15 +290,17 @@ def test_row_conv_out_of_lds(gpu_ctx, layer):
 
 
 # (cin, cout, H, W)
-WINO3_LAYERS = [(128, 24, 48, 64), (64, 16, 40, 72), (64, 64, 24, 64), (130, 24, 17, 34), (18, 40, 7, 66), (32, 16, 192, 256), (20, 64, 13, 128), (16, 8, 6, 64)]
+WINO3_LAYERS = [(128, 24, 48, 64), (64, 16, 40, 72), (64, 64, 24, 64), (130, 24, 17, 34), (18, 40, 7, 66), (32, 16, 192, 256), (20, 64, 13, 128), (16, 8, 6, 64), (64, 64, 9, 44)]
 
 
 @pytest.mark.parametrize("layer", WINO3_LAYERS)
 def test_minimal_filtering_3x3_rows_stationary(gpu_ctx, layer):
-    """conv_wino3.hip: 3 x 3 stride-1 convs as three 1 x 3 F(2,3) row filters with the transformed input rows kept in LDS for the
-    three output rows they feed (plan kind 15).  Same products as the wino1d kernel's three-pass form, other order of addition: 1e-5
-    relative L1 against PyTorch for every workgroup shape that fits the layer; ragged heights / widths, Cin not a multiple of 4 / 8,
-    Cout below a channel block; deterministic."""
+    """conv_wino3.hip: 3 x 3 stride-1 convs as three 1 x 3 row filters with the transformed input rows kept in LDS for the three
+    output rows they feed (plan kind 15): variants 0 .. 7 on F(2,3) tiles of two pixels (same products as the wino1d kernel's
+    three-pass form, other order of addition), variants 8 .. 15 on F(4,3) tiles of four pixels (6 products per 4 outputs and kernel
+    row; interpolation points 0, +-1, +-2: about twice the rounding error of a direct fp32 sum).  1e-5 relative L1 against PyTorch for
+    every workgroup shape that fits the layer; ragged heights / widths, Cin not a multiple of 4 / 8, Cout below a channel block;
+    deterministic."""
     cin, cout, H, W = layer
     rng = np.random.default_rng(35)
     n = 3
@@ -308,16 +310,20 @@ def test_minimal_filtering_3x3_rows_stationary(gpu_ctx, layer):
     want = _ref("conv", x, w, b, (1, 1))
     ran = 0
     try:
-        for v in range(8):
+        forms = set()
+        for v in range(16):
             os.environ["DEMON_FORCE_PLAN"] = "15,%d,1" % v
             got = gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True)
             tag = gpu_ctx.last_kernel()
             if not tag.startswith("wino3rows<"):
                 continue   # the shape does not fit this layer (channel block vs Cout, too many empty tile slots)
             ran += 1
+            forms.add(tag.split(",")[0])
             err = rel_l1(got, want)
             assert err < 1e-5, "variant %d (%s): rel L1 %.3e" % (v, tag, err)
             np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True))
         assert ran >= 1, layer
+        if W % 4 == 0 and (cout > 16 or W >= 128):   # (the one-channel-block F(4,3) shapes are 256 pixels wide)
+            assert forms == {"wino3rows<t3x3", "wino3rows<f4t3x3"}, forms   # both forms ran
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)

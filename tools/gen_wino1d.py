@@ -15,7 +15,8 @@ import os
 from fractions import Fraction as Fr
 from math import lcm
 
-POINTS = {2: [0, -1], 3: [0, 1, -1], 4: [0, 1, -1, 2], 5: [0, 1, -1, 2, -2], 1: []}
+POINTS = {2: [0, -1], 3: [0, 1, -1], 4: [0, 1, -1, 2], 5: [0, 1, -1, 2, -2], 1: []}   # F(2,r): r finite points (+ infinity)
+POINTS_BY_COUNT = {5: [0, 1, -1, 2, -2]}                                                # F(4,3): m + r - 2 finite points
 
 
 def toom(m, r):
@@ -23,7 +24,7 @@ def toom(m, r):
     a = m + r - 1
     if r == 1:   # F(2,1): two outputs, one tap: o0 = d0 g, o1 = d1 g
         return [[Fr(1), Fr(0)], [Fr(0), Fr(1)]], [[Fr(1)], [Fr(1)]], [[Fr(1), Fr(0)], [Fr(0), Fr(1)]]
-    pts = [Fr(p) for p in POINTS[r]]
+    pts = [Fr(p) for p in (POINTS[r] if m == 2 else POINTS_BY_COUNT[a - 1])]
     assert len(pts) == a - 1
 
     def polymul(p, q):
@@ -104,8 +105,8 @@ def check(AT, G, BT, taps, stride, win):
         g = [Fr(rnd.randint(-9, 9)) for _ in range(taps)]
         U = [sum(G[e][t] * g[t] for t in range(taps)) for e in range(len(G))]
         T = [sum(BT[e][n] * d[n] for n in range(win)) for e in range(len(G))]
-        Y = [sum(AT[k][e] * U[e] * T[e] for e in range(len(G))) for k in range(2)]
-        ref = [sum(d[stride * k + t] * g[t] for t in range(taps)) for k in range(2)]
+        Y = [sum(AT[k][e] * U[e] * T[e] for e in range(len(G))) for k in range(len(AT))]
+        ref = [sum(d[stride * k + t] * g[t] for t in range(taps)) for k in range(len(AT))]
         assert Y == ref, (taps, stride, Y, ref)
 
 
@@ -194,6 +195,27 @@ def render():
         out.append("    }")
         out.append("};")
         out.append("")
+    # F(4,3): four consecutive outputs of a 3-tap stride-1 filter from a window of six with 6 products instead of 12 (conv_wino3.hip)
+    AT, G, BT = toom(4, 3)
+    AT, G = normalise(AT, G)
+    check(AT, G, BT, 3, 1, 6)
+    out.append("// 3 taps, stride 1, FOUR outputs per window of 6 inputs: 6 products instead of 12 (points 0, +-1, +-2, infinity)")
+    out.append("struct Wino43 {")
+    out.append("    static constexpr int TAPS = 3, STRIDE = 1, NUV = 6, WIN = 6, OUT = 4;")
+    out.append("    static __host__ __device__ __forceinline__ float g(int e, int t) {")
+    out.append("        constexpr float G[NUV][TAPS] = {%s};" % ", ".join("{" + ", ".join(cf(v) for v in row) + "}" for row in G))
+    out.append("        return G[e][t];")
+    out.append("    }")
+    out.append("    static __device__ __forceinline__ void input(const float (&d)[WIN], float (&t)[NUV]) {")
+    out.append(emit_input(BT, 6, 4))
+    out.append("    }")
+    names = ["m[%d]" % e for e in range(6)]
+    out.append("    static __device__ __forceinline__ void output(const float (&m)[NUV], float (&o)[OUT]) {")
+    for k in range(4):
+        out.append("        o[%d] = %s;" % (k, linear(AT[k], names)))
+    out.append("    }")
+    out.append("};")
+    out.append("")
     out.append("}  // namespace demon")
     return "\n".join(out) + "\n"
 

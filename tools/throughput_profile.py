@@ -25,6 +25,8 @@ ctx.run_full(n, 3); ctx.synchronize()
 def share(tag):
     if tag.startswith("wino_deconv"):
         return 9 / 16
+    if tag.startswith("wino3rows<f4"):
+        return 0.5
     m = re.match(r"(?:wino1d|wino3rows|conv_row<32x128,)<?t(\d+)", tag)
     if m:
         t = int(m.group(1))
