@@ -346,6 +346,10 @@ def main():
                     return 9.0 / 16.0            # F(2,2) x F(2,2) per sub-pixel class
                 if tag.startswith("wino3rows<f4"):
                     return 6.0 / 12.0            # F(4,3) row filters
+                if tag.startswith("wino4<t3"):
+                    return 6.0 / 12.0            # F(4,3)
+                if tag.startswith("wino4<t5"):
+                    return 11.0 / 20.0           # polyphase F(4,3) + F(4,2)
                 m = re.match(r"(?:wino1d|wino3rows|conv_row<32x128,|wino1d_chain)<?t(\d+)", tag)
                 if m:
                     taps = int(m.group(1))
@@ -398,7 +402,7 @@ def main():
             fam_achieved = flops_executed / (ms * 1e-3) / 1e12
             result["pipeline_mfma_executed_frac"] = result["pipeline_mfma_frac"] * flops_executed / flops
             result["roofline_family"] = {
-                "kernel": "all conv / deconv / dense launches (wino_deconv, wino1d, wino3rows, conv_frag, conv_frag_chain, conv_stream, conv_stream_chain, conv_patch, deconv4, conv_pair, conv_thin, conv_row, dense_stream, conv_mfma, conv_small kernels)",
+                "kernel": "all conv / deconv / dense launches (wino_deconv, wino1d, wino3rows, wino4, conv_frag, conv_frag_chain, conv_stream, conv_stream_chain, conv_patch, deconv4, conv_pair, conv_thin, conv_row, dense_stream, conv_mfma, conv_small kernels)",
                 "note": "`achieved` / `frac` count the multiply-adds the matrix pipe executes (the minimal-filtering kernels of conv_wino.hip / conv_row.hip compute the same sums with fewer products); `algorithmic_*` price 2 * MAC of the direct convolutions (BASELINE.md section 2) over the same time",
                 "bound": "mfma", "achieved": fam_achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": fam_achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,

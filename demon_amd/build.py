@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdemon_hip.so")
-SOURCES = ["demon_api.hip", "conv_mfma.hip", "conv_patch.hip", "conv_small.hip", "conv_pair.hip", "conv_stream.hip", "conv_frag.hip", "conv_wino.hip", "conv_wino3.hip", "dense_stream.hip", "conv_thin.hip", "conv_row.hip", "ops.hip"]
+SOURCES = ["demon_api.hip", "conv_mfma.hip", "conv_patch.hip", "conv_small.hip", "conv_pair.hip", "conv_stream.hip", "conv_frag.hip", "conv_wino.hip", "conv_wino3.hip", "conv_wino4.hip", "dense_stream.hip", "conv_thin.hip", "conv_row.hip", "ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -55,7 +55,7 @@ def build(force=False, verbose=False, extra_flags=(), tag=""):
         if force or _needs_build(o, [s] + headers):
             # conv_wino.hip: the SLP vectoriser packs the +-1 transforms into v_pk_add_f32 plus register shuffles -- more VALU issue
             # slots beside the fp32 MFMAs, which share the SIMD with the vector ALU
-            per_file = ["-fno-slp-vectorize"] if src in ("conv_wino.hip", "conv_wino3.hip", "conv_row.hip") else []
+            per_file = ["-fno-slp-vectorize"] if src in ("conv_wino.hip", "conv_wino3.hip", "conv_wino4.hip", "conv_row.hip") else []
             jobs.append([hipcc] + FLAGS + per_file + list(extra_flags) + ["-c", s, "-o", o])
 
     def run(cmd):

@@ -65,6 +65,15 @@ struct Layer {
     // F(4,3) weights of the 3 x 3 stride-1 layers for conv_wino3.hip: U43[ky][e][Cin4][Mpad], 6 planes per kernel row
     float *d_w3 = nullptr;
     mutable bool w3_dirty = true;
+    // four-outputs-per-window weights of the 3-tap stride-1 / 5-tap stride-2 1-D layers for conv_wino4.hip: U[e][Cin4][Mpad], 6 / 11 planes
+    float *d_w4 = nullptr;
+    mutable bool w4_dirty = true;
+    int wino4_kind_of() const
+    {
+        if (kind != CONV || scale || Cin < 16 || (kh != 1 && kw != 1) || (kh == 1 && kw == 1)) return -1;
+        if ((kw == 1 && sw != 1) || (kh == 1 && sh != 1)) return -1;
+        return wino4_kind(kw == 1 ? kh : kw, kw == 1 ? sh : sw);
+    }
     // weight-streaming dense kernel (dense_stream.hip): the weights re-blocked to [Mpad / 128][Cin][128]
     float *d_wd = nullptr;
     mutable bool wd_dirty = true;
@@ -301,6 +310,12 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
         L->d_w1 = dev_alloc(c, sizeof(float) * nu);
         if (!L->d_w1 || hipMemset(L->d_w1, 0, sizeof(float) * nu) != hipSuccess) return false;
         L->w1_dirty = true;
+        if (L->wino4_kind_of() >= 0) {
+            const size_t n4 = ((size_t)wino4_nuv(L->wino4_kind_of()) * L->Cin4() + 16) * L->Mpad;
+            L->d_w4 = dev_alloc(c, sizeof(float) * n4);
+            if (!L->d_w4 || hipMemset(L->d_w4, 0, sizeof(float) * n4) != hipSuccess) return false;
+            L->w4_dirty = true;
+        }
         if (L->wino1d_cross() == 3 && L->in.W % 4 == 0 && L->in.W >= 32) {
             const size_t n3 = ((size_t)3 * 6 * L->Cin4() + 16) * L->Mpad;
             L->d_w3 = dev_alloc(c, sizeof(float) * n3);
@@ -377,6 +392,7 @@ int upload_kernel(demon_ctx *c, Layer *L, const float *w)
     L->wf_dirty = true;
     L->w1_dirty = true;
     L->w3_dirty = true;
+    L->w4_dirty = true;
     L->wd_dirty = true;
     return DEMON_OK;
 }
@@ -620,6 +636,10 @@ void refresh_stream_weights(const Layer *L, hipStream_t s)
         launch_wino3_repack43(L->d_w3, L->d_wp, L->Cin, L->Cin4(), L->Mpad, s);
         L->w3_dirty = false;
     }
+    if (L->d_w4 && L->w4_dirty) {   // four-outputs-per-window weights of conv_wino4.hip
+        launch_wino4_repack(L->d_w4, L->d_wp, L->wino4_kind_of(), L->Cin, L->Cin4(), L->Mpad, s);
+        L->w4_dirty = false;
+    }
     if (L->d_wd && L->wd_dirty) {   // re-blocked weights of the weight-streaming dense kernel (dense_stream.hip)
         launch_dense_repack(L->d_wd, L->d_wp, L->Cin, L->Mpad, s);
         L->wd_dirty = false;
@@ -774,6 +794,31 @@ bool run_wino3(const Layer *L, const ConvArgs &a, int variant, hipStream_t s)
     return true;
 }
 
+// k x 1 / 1 x k convs with four outputs per window (conv_wino4.hip), plan kind 16: variant = workgroup shape
+bool wino4_applies(const Layer *L) { return L->d_w4 != nullptr && L->wino4_kind_of() >= 0; }
+
+bool fill_wino4_args(const Layer *L, const ConvArgs &a, int variant, Wino4Args &w)
+{
+    w.in = a.in; w.out = a.out; w.wu = L->d_w4; w.bias = a.bias;
+    w.N = a.N; w.Cin = L->Cin; w.Cin4 = L->Cin4(); w.H = a.H; w.W = a.W; w.Ho = a.Ho; w.Wo = a.Wo; w.in_n_stride = a.in_n_stride;
+    w.Cout = L->Cout; w.Mpad = L->Mpad; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
+    w.act = a.act; w.xcd = a.xcd;
+    w.pad = L->wino1d_axis() == 0 ? L->ph : L->pw;
+    return wino4_plan_geometry(w, L->wino4_kind_of(), variant, L->wino1d_axis());
+}
+
+bool run_wino4(const Layer *L, const ConvArgs &a, int variant, hipStream_t s)
+{
+    if (!wino4_applies(L)) return false;
+    refresh_stream_weights(L, s);
+    Wino4Args w;
+    if (!fill_wino4_args(L, a, variant, w)) return false;
+    if (!launch_wino4(w, L->wino4_kind_of(), variant, L->wino1d_axis(), s)) return false;
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino4<t%d,v%d>", L->wino1d_axis() == 0 ? L->kh : L->kw, variant);
+    g_last_kernel = g_kernel_tag;
+    return true;
+}
+
 // weight-streaming dense layer (dense_stream.hip), plan kind 11: ksplit = K slices across workgroups (dense_reduce_kernel adds them)
 bool dense_stream_applies(const Layer *L) { return L->d_wd != nullptr; }
 
@@ -874,6 +919,8 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
                 if (wino1d_applies(L) && run_wino1d(L, a, tile, clamp_split(ks % 1000), s)) return;
             } else if (kind == 15) {
                 if (run_wino3(L, a, tile, s)) return;
+            } else if (kind == 16) {
+                if (run_wino4(L, a, tile, s)) return;
             } else if (kind == 13) {
                 if (row_applies(L) && run_row(L, a, s)) return;
             } else if (kind == 12) {
@@ -917,6 +964,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             if (t.kind == 12 && thin_applies(L) && run_thin(L, a, s)) return;
             if (t.kind == 13 && row_applies(L) && run_row(L, a, s)) return;
             if (t.kind == 15 && run_wino3(L, a, t.tile, s)) return;
+            if (t.kind == 16 && run_wino4(L, a, t.tile, s)) return;
             if (t.kind == 11 && dense_stream_applies(L) && run_dense_stream(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
@@ -1094,6 +1142,12 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
                 if (wgs * ks < 64) continue;
                 cands.push_back({10, v, ks});
             }
+        }
+    }
+    if (wino4_applies(L)) {
+        for (int v = 0; v < WINO4_VARIANTS; ++v) {
+            Wino4Args w;
+            if (fill_wino4_args(L, a, v, w) && wino4_workgroups(w, v) >= 128) cands.push_back({16, v, 1});
         }
     }
     if (wino3_applies(L)) {
@@ -2153,7 +2207,7 @@ void slab_arrived(demon_ctx *c)
 {
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
-    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->w1_dirty = true; L->w3_dirty = true; L->wd_dirty = true; }
+    for (auto &L : c->layers) { L->have_kernel = L->have_bias = true; L->wf_dirty = true; L->w1_dirty = true; L->w3_dirty = true; L->w4_dirty = true; L->wd_dirty = true; }
 }
 }  // namespace
 extern "C" {
@@ -2347,8 +2401,9 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
     // 13 = 1 x 7 / 1 x 9 stride-2 conv with <= 32 channels, whole reduction out of LDS (conv_row.hip; tile 0)
     // 14 = marker on the k x 1 layer of a conv_pair.hip pair: the fused launch was measured faster at this batch size (the layer alone: heuristics)
     // 15 = 3 x 3 stride-1 conv, transformed input rows stationary (conv_wino3.hip; tile = workgroup shape)
-    if (kind < 0 || kind > 15 || kind == 2 || kind == 9 || tile < 0 ||
-        tile >= (kind == 15 ? (int)WINO3_VARIANTS : kind >= 12 ? 1 : kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
+    // 16 = k x 1 / 1 x k conv with four outputs per window (conv_wino4.hip: 3 taps stride 1, 5 taps stride 2; tile = workgroup shape)
+    if (kind < 0 || kind > 16 || kind == 2 || kind == 9 || tile < 0 ||
+        tile >= (kind == 16 ? (int)WINO4_VARIANTS : kind == 15 ? (int)WINO3_VARIANTS : kind >= 12 ? 1 : kind == 11 ? (int)DENSE_VARIANTS : kind == 10 ? (int)WINO1D_VARIANTS : kind == 8 ? (int)WINO_VARIANTS : (kind == 1 ? (int)PTILE_COUNT : ((kind == 4 || kind == 7) ? (int)STREAM_VARIANTS : ((kind == 5 || kind == 6) ? (int)FRAG_VARIANTS : (int)TILE_COUNT)))) || ksplit < 0)
         return fail(c, DEMON_ERR_INVALID, "bad plan entry");
     if (kind != 1 && ksplit >= 1000)   // (until round 3 "+ 1000" on kinds 0 / 4 / 5 selected a split-K form that no longer exists)
         return fail(c, DEMON_ERR_INVALID, "ksplit >= 1000 is only meaningful for the patch-staged kernel (pixel-tile shape)");
@@ -2358,6 +2413,7 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
             if (kind == 3 && !small_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the small-Cout kernel does not apply to this layer");
             if (kind == 8 && !wino_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the minimal-filtering kernel applies to transposed convs only");
             if (kind == 10 && !wino1d_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "no 1-D minimal-filtering form for this layer");
+            if (kind == 16 && !wino4_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_wino4.hip applies to k x 1 / 1 x k convs with 3 taps stride 1 or 5 taps stride 2 and >= 16 input channels only");
             if (kind == 15 && !wino3_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_wino3.hip applies to 3 x 3 stride-1 convs with >= 16 input channels and rows of even length only");
             if (kind == 13 && !row_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_row.hip applies to 1 x 7 / 1 x 9 stride-2 convs with at most 32 channels on both sides only");
             if (kind == 12 && !thin_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_thin.hip applies to the 9 x 1 stride-2 first layer (Cin <= 6, Cout <= 32) only");

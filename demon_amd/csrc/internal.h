@@ -318,6 +318,33 @@ bool wino3_plan_geometry(Wino3Args &a, int variant);
 long wino3_workgroups(const Wino3Args &a, int variant);
 bool launch_wino3(const Wino3Args &a, int variant, hipStream_t stream);   // false: nothing was launched
 
+// ---- k x 1 / 1 x k convs with FOUR outputs per window: F(4,3) (3 taps, stride 1), F(4,3) + F(4,2) (5 taps, stride 2) (conv_wino4.hip) ----
+struct Wino4Args {
+    const float *in;
+    float *out;
+    const float *wu;     // transformed weights U[e][Cin4][Mpad] (wino4_repack_kernel)
+    const float *bias;
+    int N, Cin, Cin4, H, W, Ho, Wo;
+    long in_n_stride;
+    int Cout, Mpad;
+    long out_n_stride, out_plane;
+    int act, pad, csteps;                // zeros in front of the first sample along the filter axis; K-steps of 4 KG input channels
+    int rows_y, cols_x;                  // workgroup tiles per image: blocks of TN lines x blocks of 16 WN positions (conv_wino4.hip)
+    int sub_shift, pb_shift;             // narrow maps: 2^sub_shift lines side by side in a block, 2^pb_shift positions per line
+    int xcd;
+    unsigned m_colsx, m_rowsy;
+};
+constexpr int WINO4_VARIANTS = 9;    // workgroup shapes (waves along Cout x waves along positions x lines per wave x K groups per step)
+int wino4_kind(int taps, int stride);   // 0: 3 taps stride 1, 1: 5 taps stride 2, -1: none
+int wino4_nuv(int kind);
+int wino4_variant_bm(int v);
+int wino4_variant_kg(int v);
+bool wino4_variant_ok(int kind, int v);
+bool wino4_plan_geometry(Wino4Args &a, int kind, int variant, int axis);
+long wino4_workgroups(const Wino4Args &a, int variant);
+void launch_wino4_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, hipStream_t s);
+bool launch_wino4(const Wino4Args &a, int kind, int variant, int axis, hipStream_t stream);   // false: nothing was launched
+
 // ---- weight-streaming dense layer at small batch (dense_stream.hip): dense5 (v2), motion_fc1 -----------------------------------------------
 struct DenseArgs {
     const float *x;      // activations [N][x_n_stride], K consecutive floats per sample

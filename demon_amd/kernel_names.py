@@ -71,6 +71,11 @@ def kernel_tag(name):
             return "wino3rows<f4t3x3,v%d>" % shapes4.get(shape, -1)
         shapes3 = {(2, 2, 4, 1): 0, (2, 4, 4, 1): 1, (4, 1, 4, 1): 2, (4, 2, 4, 1): 3, (1, 4, 4, 1): 4, (1, 4, 2, 2): 5, (2, 2, 2, 2): 6, (4, 1, 2, 2): 7}
         return "wino3rows<t3x3,v%d>" % shapes3.get(shape, -1)
+    m = re.search(r"wino4_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        kind, axis, wm, wn, tn, kg = map(int, m.groups())
+        shapes4 = {(4, 1, 4, 1): 0, (4, 1, 2, 2): 1, (2, 2, 4, 1): 2, (2, 2, 2, 2): 3, (4, 2, 2, 2): 4, (4, 2, 4, 1): 5, (4, 1, 1, 4): 6, (2, 2, 1, 4): 7, (2, 2, 2, 1): 8}
+        return "wino4<t%d,v%d>" % (3 if kind == 0 else 5, shapes4.get((wm, wn, tn, kg), -1))
     m = re.search(r"conv_row_kernel<(\d+), ", name)
     if m:
         return "conv_row<32x128,t%d>" % (3 + 2 * int(m.group(1)))
@@ -99,6 +104,8 @@ def rocprof_kernel_name(tag):
         return "demon::conv_patch_kernel<%s, ...> (%sx%s tile, %s taps)" % (dims[0], dims[0], dims[1], rest.rstrip(">").split(",t")[-1])
     if fam == "wino_deconv" and len(dims) == 2:
         return "demon::wino_deconv_kernel<%d, ...> (16 channels x %s tiles per workgroup)" % (int(dims[1]) // 16, dims[1])
+    if fam == "wino4":
+        return "demon::wino4_kernel<...> (%s)" % rest.rstrip(">")
     if fam == "wino3rows":
         return "demon::wino3_rows_kernel<...> (%s)" % rest.rstrip(">")
     if fam == "wino1d":

@@ -112,7 +112,9 @@ int demon_autotune(demon_ctx *ctx, int n);
  *        6 / 7 on the k x 1 layer of a stride-1 pair: the pair runs as ONE chained launch of conv_frag / conv_stream variant `tile`;
  *        14 marker on the k x 1 layer of a conv_pair.hip pair: the fused launch measured faster at this batch size;
  *        15 3 x 3 stride-1 conv as three 1 x 3 minimal-filtering row filters with the transformed input rows stationary
- *           (conv_wino3.hip; tile = workgroup shape 0..7);
+ *           (conv_wino3.hip; tile = workgroup shape 0..7 on F(2,3) tiles, 8..15 on F(4,3) tiles),
+ *        16 k x 1 / 1 x k conv with four outputs per window (conv_wino4.hip: F(4,3) for 3 taps stride 1, F(4,3) + F(4,2) for 5 taps
+ *           stride 2; tile = workgroup shape 0..7);
  *   tile = tile / variant id of that kernel; ksplit = K slices across workgroups, combined by a conv_splitk_reduce launch.
  *   demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
 int demon_num_layers(const demon_ctx *ctx);

@@ -98,6 +98,7 @@ def test_shipped_plans_are_well_formed():
     limits[8] = int(re.search(r"WINO_VARIANTS\s*=\s*(\d+)", src).group(1))      # minimal-filtering transposed conv (conv_wino.hip)
     limits[10] = int(re.search(r"WINO1D_VARIANTS\s*=\s*(\d+)", src).group(1))   # 1-D minimal filtering; 9 is not a kernel
     limits[15] = int(re.search(r"WINO3_VARIANTS\s*=\s*(\d+)", src).group(1))    # 3 x 3 stride 1, transformed input rows stationary (conv_wino3.hip)
+    limits[16] = int(re.search(r"WINO4_VARIANTS\s*=\s*(\d+)", src).group(1))    # k x 1 / 1 x k, four outputs per window (conv_wino4.hip)
     limits[13] = 1                                                               # 1 x 7 / 1 x 9 stride-2 conv out of LDS (conv_row.hip)
     limits[12] = 1                                                               # first layer, weights in registers (conv_thin.hip)
     limits[11] = 2                                                               # weight-streaming dense layer (dense_stream.hip)

@@ -25,7 +25,7 @@ PLANS = sorted(glob.glob(os.path.join(ROOT, "demon_amd", "tuned", "plan_*.json")
 KEYS = ("predict_flow5", "predict_conf5", "predict_flow2", "predict_conf2", "predict_depth2", "predict_normal2", "predict_rotation",
         "predict_translation", "predict_scale", "predict_depth0")
 FAMILY = {0: ("conv_mfma<",), 1: ("conv_patch<", "deconv4<"), 3: ("conv_small",), 4: ("conv_stream<",), 5: ("conv_frag<",),
-          6: ("conv_frag_chain<",), 7: ("conv_stream_chain<",), 8: ("wino_deconv<",), 10: ("wino1d<",), 11: ("dense_stream<",), 12: ("conv_thin<",), 13: ("conv_row<",), 15: ("wino3rows<",)}
+          6: ("conv_frag_chain<",), 7: ("conv_stream_chain<",), 8: ("wino_deconv<",), 10: ("wino1d<",), 11: ("dense_stream<",), 12: ("conv_thin<",), 13: ("conv_row<",), 15: ("wino3rows<",), 16: ("wino4<",)}
 
 
 def _weights(version, height, width):

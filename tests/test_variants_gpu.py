@@ -327,3 +327,40 @@ def test_minimal_filtering_3x3_rows_stationary(gpu_ctx, layer):
             assert forms == {"wino3rows<t3x3", "wino3rows<f4t3x3"}, forms   # both forms ran
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+# (cin, cout, kh, kw, sh, sw, H, W)
+WINO4_LAYERS = [(64, 64, 3, 1, 1, 1, 48, 64), (64, 64, 1, 3, 1, 1, 48, 64), (128, 128, 3, 1, 1, 1, 24, 32), (128, 128, 1, 3, 1, 1, 24, 32),
+                (64, 128, 5, 1, 2, 1, 48, 64), (128, 128, 1, 5, 1, 2, 24, 64), (128, 256, 5, 1, 2, 1, 24, 32), (256, 256, 1, 5, 1, 2, 12, 32),
+                (18, 40, 3, 1, 1, 1, 13, 70), (30, 24, 1, 5, 1, 2, 6, 256), (22, 36, 5, 1, 2, 1, 35, 66), (20, 16, 1, 3, 1, 1, 7, 64), (256, 256, 3, 1, 1, 1, 12, 16),
+                (256, 256, 1, 3, 1, 1, 12, 16), (24, 48, 1, 5, 1, 2, 9, 32)]
+
+
+@pytest.mark.parametrize("layer", WINO4_LAYERS)
+def test_minimal_filtering_four_outputs_per_window(gpu_ctx, layer):
+    """conv_wino4.hip (plan kind 16): k x 1 / 1 x k layers with four outputs per window -- F(4,3) for 3 taps stride 1 (6 products
+    instead of 12), polyphase F(4,3) + F(4,2) for 5 taps stride 2 (11 instead of 20); interpolation points 0, +-1, +-2 / 0, +-1, 2
+    (tables checked in exact rationals by tools/gen_wino1d.py).  1e-5 relative L1 against PyTorch for every workgroup shape that fits;
+    ragged sizes, Cin not a multiple of 4 / 8 / 16, Cout not a multiple of the channel block; deterministic."""
+    cin, cout, kh, kw, sh, sw, H, W = layer
+    rng = np.random.default_rng(36)
+    n = 3
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("conv", x, w, b, (sh, sw))
+    ran = 0
+    try:
+        for v in range(9):
+            os.environ["DEMON_FORCE_PLAN"] = "16,%d,1" % v
+            got = gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
+            tag = gpu_ctx.last_kernel()
+            if not tag.startswith("wino4<"):
+                continue   # shape not built for this filter (accumulator budget), Cout not a multiple of its channel block, too much waste
+            ran += 1
+            err = rel_l1(got, want)
+            assert err < 1e-5, "variant %d (%s): rel L1 %.3e" % (v, tag, err)
+            np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True))
+        assert ran >= 1, layer
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)

@@ -16,7 +16,7 @@ from fractions import Fraction as Fr
 from math import lcm
 
 POINTS = {2: [0, -1], 3: [0, 1, -1], 4: [0, 1, -1, 2], 5: [0, 1, -1, 2, -2], 1: []}   # F(2,r): r finite points (+ infinity)
-POINTS_BY_COUNT = {5: [0, 1, -1, 2, -2]}                                                # F(4,3): m + r - 2 finite points
+POINTS_BY_COUNT = {5: [0, 1, -1, 2, -2], 4: [0, 1, -1, 2]}                               # F(4,3) / F(4,2): m + r - 2 finite points
 
 
 def toom(m, r):
@@ -81,6 +81,51 @@ def kind_matrices(taps, stride):
         for a_ in range(ro + 1):
             BT[ne + i][2 * a_ + 1] = BTo[i][a_]
     return AT, G, BT, win
+
+
+def kind_matrices4(taps, stride):
+    """FOUR outputs per window: AT (4 x NUV), G (NUV x taps), BT (NUV x WIN); stride 2 = polyphase F(4,re) + F(4,ro)"""
+    if stride == 1:
+        AT, G, BT = toom(4, taps)
+        return AT, G, BT, taps + 3
+    re, ro = (taps + 1) // 2, taps // 2
+    win = 2 * 4 + taps - 2
+    ATe, Ge, BTe = toom(4, re)
+    ATo, Go, BTo = toom(4, ro)
+    ne, no = len(Ge), len(Go)
+    AT = [ATe[k] + ATo[k] for k in range(4)]
+    G = [[Fr(0)] * taps for _ in range(ne + no)]
+    BT = [[Fr(0)] * win for _ in range(ne + no)]
+    for i in range(ne):
+        for b in range(re):
+            G[i][2 * b] = Ge[i][b]
+        for a_ in range(re + 3):
+            BT[i][2 * a_] = BTe[i][a_]
+    for i in range(no):
+        for b in range(ro):
+            G[ne + i][2 * b + 1] = Go[i][b]
+        for a_ in range(ro + 3):
+            BT[ne + i][2 * a_ + 1] = BTo[i][a_]
+    return AT, G, BT, win
+
+
+def render4(name, taps, stride, comment):
+    AT, G, BT, win = kind_matrices4(taps, stride)
+    AT, G = normalise(AT, G)
+    check(AT, G, BT, taps, stride, win)
+    nuv = len(G)
+    out = ["// " + comment, "struct %s {" % name,
+           "    static constexpr int TAPS = %d, STRIDE = %d, NUV = %d, WIN = %d, OUT = 4;" % (taps, stride, nuv, win),
+           "    static __host__ __device__ __forceinline__ float g(int e, int t) {",
+           "        constexpr float G[NUV][TAPS] = {%s};" % ", ".join("{" + ", ".join(cf(v) for v in row) + "}" for row in G),
+           "        return G[e][t];", "    }",
+           "    static __device__ __forceinline__ void input(const float (&d)[WIN], float (&t)[NUV]) {", emit_input(BT, win, name), "    }"]
+    names = ["m[%d]" % e for e in range(nuv)]
+    out.append("    static __device__ __forceinline__ void output(const float (&m)[NUV], float (&o)[OUT]) {")
+    for k in range(4):
+        out.append("        o[%d] = %s;" % (k, linear(AT[k], names)))
+    out += ["    }", "};", ""]
+    return out
 
 
 def normalise(AT, G):
@@ -195,27 +240,9 @@ def render():
         out.append("    }")
         out.append("};")
         out.append("")
-    # F(4,3): four consecutive outputs of a 3-tap stride-1 filter from a window of six with 6 products instead of 12 (conv_wino3.hip)
-    AT, G, BT = toom(4, 3)
-    AT, G = normalise(AT, G)
-    check(AT, G, BT, 3, 1, 6)
-    out.append("// 3 taps, stride 1, FOUR outputs per window of 6 inputs: 6 products instead of 12 (points 0, +-1, +-2, infinity)")
-    out.append("struct Wino43 {")
-    out.append("    static constexpr int TAPS = 3, STRIDE = 1, NUV = 6, WIN = 6, OUT = 4;")
-    out.append("    static __host__ __device__ __forceinline__ float g(int e, int t) {")
-    out.append("        constexpr float G[NUV][TAPS] = {%s};" % ", ".join("{" + ", ".join(cf(v) for v in row) + "}" for row in G))
-    out.append("        return G[e][t];")
-    out.append("    }")
-    out.append("    static __device__ __forceinline__ void input(const float (&d)[WIN], float (&t)[NUV]) {")
-    out.append(emit_input(BT, 6, 4))
-    out.append("    }")
-    names = ["m[%d]" % e for e in range(6)]
-    out.append("    static __device__ __forceinline__ void output(const float (&m)[NUV], float (&o)[OUT]) {")
-    for k in range(4):
-        out.append("        o[%d] = %s;" % (k, linear(AT[k], names)))
-    out.append("    }")
-    out.append("};")
-    out.append("")
+    # four outputs per window (conv_wino3.hip, conv_wino4.hip)
+    out += render4("Wino43", 3, 1, "3 taps, stride 1, FOUR outputs per window of 6 inputs: 6 products instead of 12 (points 0, +-1, +-2, infinity)")
+    out += render4("Wino4K5S2", 5, 2, "5 taps, stride 2, FOUR outputs per window of 11 inputs: polyphase F(4,3) + F(4,2) = 11 products instead of 20")
     out.append("}  // namespace demon")
     return "\n".join(out) + "\n"
 

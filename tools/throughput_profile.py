@@ -25,8 +25,10 @@ ctx.run_full(n, 3); ctx.synchronize()
 def share(tag):
     if tag.startswith("wino_deconv"):
         return 9 / 16
-    if tag.startswith("wino3rows<f4"):
+    if tag.startswith("wino3rows<f4") or tag.startswith("wino4<t3"):
         return 0.5
+    if tag.startswith("wino4<t5"):
+        return 11 / 20
     m = re.match(r"(?:wino1d|wino3rows|conv_row<32x128,)<?t(\d+)", tag)
     if m:
         t = int(m.group(1))
