@@ -464,23 +464,32 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
         }
         const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, NREC, 0x00020000);
         const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + ((long)ky * NUV * a.Cin4 + (long)cs * CKS) * a.Mpad), 0, NREC, 0x00020000);
+        // channels past Cin (last K-step of a cross tap, Cin not a multiple of 4 KG) are NOT read -- the planes behind the last channel
+        // of the last image may lie behind the end of the allocation: their units load from the out-of-range offset, i.e. zeros
+        auto units = [&](auto last_step) {   // (the masked form only in the K-steps that need it: no extra VALU in the others)
+            constexpr bool LAST = decltype(last_step)::value;
 #pragma unroll
-        for (int i = 0; i < UNITS; ++i)
+            for (int i = 0; i < UNITS; ++i) {
+                const int dead = (LAST && !((lastmask >> i) & 1u)) ? OOB : 0;   // (or-ed into the offsets: OOB covers every bit of a valid offset)
 #pragma unroll
-            for (int e = 0; e < NLD; ++e) {
-                if constexpr (VW == 4) {
-                    const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, goff[i][e], 0, 0));
+                for (int e = 0; e < NLD; ++e) {
+                    if constexpr (VW == 4) {
+                        const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, goff[i][e] | dead, 0, 0));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) preg[i][4 * e + j] = v[j];
-                } else if constexpr (VW == 2) {
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prsrc, goff[i][e], 0, 0));
-                    preg[i][2 * e] = v[0];
-                    preg[i][2 * e + 1] = v[1];
-                } else {
-                    preg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][e], 0, 0));
+                        for (int j = 0; j < 4; ++j) preg[i][4 * e + j] = v[j];
+                    } else if constexpr (VW == 2) {
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prsrc, goff[i][e] | dead, 0, 0));
+                        preg[i][2 * e] = v[0];
+                        preg[i][2 * e + 1] = v[1];
+                    } else {
+                        preg[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][e] | dead, 0, 0));
+                    }
                 }
             }
+        };
+        if (MASK && cs == a.csteps - 1) units(std::true_type{});
+        else units(std::false_type{});
 #pragma unroll
         for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
     };

@@ -127,41 +127,42 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     auto load_tiles = [&](float (&preg)[UNITS][PWD], floatx4 (&areg)[APER], int cs) {
         const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, NREC, 0x00020000);
         const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)cs * CKS * a.Mpad), 0, NREC, 0x00020000);
+        // channels past Cin (last K-step, Cin not a multiple of 4 KG) are NOT read -- the planes behind the last channel of the last
+        // image may lie behind the end of the allocation: their units load from the out-of-range offset, i.e. zeros
+        auto units = [&](auto last_step) {   // (the masked form only in the one K-step that needs it: no extra VALU in the others)
+            constexpr bool LAST = decltype(last_step)::value;
 #pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            if constexpr (F4) {
-                preg[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][0], 0, 0));
-                const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, goff[i][1], 0, 0));
+            for (int i = 0; i < UNITS; ++i) {
+                const int dead = (LAST && !((lastmask >> i) & 1u)) ? OOB : 0;   // (or-ed into the offsets: OOB covers every bit of a valid offset)
+                if constexpr (F4) {
+                    preg[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][0] | dead, 0, 0));
+                    const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, goff[i][1] | dead, 0, 0));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) preg[i][1 + j] = v[j];
-                preg[i][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][2], 0, 0));
-            } else {
+                    for (int j = 0; j < 4; ++j) preg[i][1 + j] = v[j];
+                    preg[i][5] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][2] | dead, 0, 0));
+                } else {
 #pragma unroll
-                for (int e = 0; e < 3; ++e) {
-                    const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prsrc, goff[i][e], 0, 0));
-                    preg[i][2 * e] = v[0];
-                    preg[i][2 * e + 1] = v[1];
+                    for (int e = 0; e < 3; ++e) {
+                        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prsrc, goff[i][e] | dead, 0, 0));
+                        preg[i][2 * e] = v[0];
+                        preg[i][2 * e + 1] = v[1];
+                    }
                 }
             }
-        }
+        };
+        if (MASK && cs == a.csteps - 1) units(std::true_type{});
+        else units(std::false_type{});
 #pragma unroll
         for (int i = 0; i < APER; ++i) areg[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff[i], 0, 0));
     };
     auto transform_store = [&](const float (&preg)[UNITS][PWD], const floatx4 (&areg)[APER], int buf, int cs) {
-        const bool last = MASK && cs == a.csteps - 1;   // (uniform) channels past Cin become zeros
+        (void)cs;   // (channels past Cin were loaded as zeros: their transformed values are zeros)
 #pragma unroll
         for (int i = 0; i < UNITS; ++i) {
             float d[WIN], t[NUV];
 #pragma unroll
             for (int e = 0; e < WIN; ++e) d[e] = preg[i][(F4 ? 0 : 1) + e];   // the window starts one pixel left of the tile
             K::input(d, t);
-            if constexpr (MASK) {
-                if (last) {
-                    const bool dead = !((lastmask >> i) & 1u);
-#pragma unroll
-                    for (int e = 0; e < NUV; ++e) t[e] = dead ? 0.0f : t[e];
-                }
-            }
             float *T = smem + tw[buf][i];
             if constexpr (NUNIT % NT == 0) {
 #pragma unroll
