@@ -318,6 +318,16 @@ def main():
             result["pipeline_mfma_frac"] = value / world * gflop_pair * 1e9 / (PEAK_FP32_MFMA_TFLOPS * 1e12)
         if not args.no_roofline and not boot_only:
             recs = ctx.profile_full(n, args.iterations, repeats=3)
+            # the same launches "in flight": every step timed as L concurrent replays on L streams (demon_profile_full under option
+            # tune_lanes; a launch is charged 1 / (5 L) of the time 5 launches x L streams take) -- what a launch costs in the regime
+            # the headline runs in.  The stand-alone times above are what the rocprofv3 summary of profiles/ must agree with.
+            in_flight = {}
+            if args.lanes > 1:
+                ctx.set_option("tune_lanes", args.lanes)
+                for r in ctx.profile_full(n, args.iterations, repeats=2):
+                    e = in_flight.setdefault(r["kernel"].split("+")[0], {"ms": 0.0, "flops": 0.0, "launches": 0})
+                    e["ms"] += r["ms"]; e["flops"] += r["flops"]; e["launches"] += 1
+                ctx.set_option("tune_lanes", 1)
             conv = [r for r in recs if r["flops"] > 0]          # every conv / deconv / dense launch (incl. its split-K reduce)
             ms = sum(r["ms"] for r in conv)
             flops = sum(r["flops"] for r in conv)
@@ -377,6 +387,12 @@ def main():
                               "passes; kernel only -- the conv_splitk_reduce launch that follows some launches is timed separately (splitk_reduce)",
                 }
                 e["flops_executed_per_launch"] = share * k["flops"] / k["launches"]
+                f = in_flight.get(tag)
+                if f and f["ms"] > 0:   # the same kernel with `lanes` passes in flight (see in_flight above)
+                    alg = f["flops"] / (f["ms"] * 1e-3) / 1e12
+                    e["in_flight"] = {"lanes": args.lanes, "avg_launch_ms": f["ms"] / f["launches"], "achieved": alg * share,
+                                      "frac": alg * share / PEAK_FP32_MFMA_TFLOPS, "algorithmic_frac": alg / PEAK_FP32_MFMA_TFLOPS,
+                                      "note": "every launch timed as %d concurrent replays on %d streams; a launch is charged its share of the wall time" % (args.lanes, args.lanes)}
                 if share != 1.0:
                     e["note"] = ("minimal-filtering kernel: the matrix pipe executes %.4f of the direct convolution's multiply-adds; `achieved` / `frac` "
                                  "count the executed ones (a roofline fraction, <= 1), `algorithmic_*` price the direct convolution's flops over the same time") % share
@@ -413,6 +429,15 @@ def main():
                 "avg_launch_ms": ms / len(conv), "flops_per_launch": flops / len(conv),
                 "gflop_per_pair_launched": flops / n / 1e9, "kernel_time_share": ms / total_ms,
             }
+            if in_flight:
+                fms = sum(v["ms"] for t, v in in_flight.items() if v["flops"] > 0)
+                fex = sum(v["flops"] * executed_share(t) for t, v in in_flight.items())
+                fal = sum(v["flops"] for v in in_flight.values())
+                result["roofline_family"]["in_flight"] = {
+                    "lanes": args.lanes, "ms_per_pass": sum(v["ms"] for v in in_flight.values()), "contraction_ms_per_pass": fms,
+                    "achieved": fex / (fms * 1e-3) / 1e12, "frac": fex / (fms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "algorithmic_frac": fal / (fms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                    "note": "all contraction launches of a pass, each timed as %d concurrent replays (sum of the per-launch shares; compare ms_per_step)" % args.lanes}
             result["kernel_time_shares"] = {k: round(v["ms"] / total_ms, 4) for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])[:8]}
             result["kernel_time_shares"]["conv_splitk_reduce (all)"] = round(sum(v["reduce_ms"] for v in by_kernel.values()) / total_ms, 4)
             # HBM bytes per launch cannot be read from inside the process: they come from the rocprofv3 --pmc passes of
