@@ -19,6 +19,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from demon_amd.kernel_names import kernel_tag  # noqa: E402
 
 
+# the launches bench.py's `roofline_family` counts: every kernel that carries multiply-adds of a conv / deconv / dense layer (the weight
+# re-packing kernels and the split-K reduce launches are families of their own)
+CONTRACTION_KERNELS = ("conv_mfma_kernel", "conv_patch_kernel", "deconv4_kernel", "conv_pair_kernel", "conv_stream_kernel", "conv_frag_kernel",
+                       "conv_frag_chain_kernel", "conv_stream_chain_kernel", "wino_deconv_kernel", "wino1d_kernel", "wino3_rows_kernel", "wino4_kernel",
+                       "dense_stream_kernel", "conv_thin_kernel", "conv_row_kernel", "conv_small_kernel")
+
+
 def load(d):
     """family -> counter -> values, and the same per kernel tag; `d` holds the csv of one rocprofv3 --pmc pass"""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -29,7 +36,7 @@ def load(d):
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
-            fam = "conv" if any(k in name for k in ("conv_mfma_kernel", "conv_patch_kernel", "deconv4_kernel", "conv_pair_kernel", "conv_stream_kernel", "conv_frag_kernel", "conv_frag_chain_kernel", "conv_stream_chain_kernel", "wino_deconv_kernel", "wino1d_kernel", "dense_stream_kernel", "conv_thin_kernel", "conv_row_kernel")) else name.split("(")[0].replace("demon::", "")
+            fam = "conv" if any(k in name for k in CONTRACTION_KERNELS) else name.split("(")[0].replace("demon::", "")
             agg[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
             agg["kernel:" + kernel_tag(name)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
