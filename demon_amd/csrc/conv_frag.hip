@@ -385,10 +385,9 @@ static void launch_frag_instance(const StreamArgs &s, dim3 grid, hipStream_t str
     constexpr size_t red = KW > 1 ? sizeof(float) * KW * WM * WN * TM * TN * 16 * 64 : 0;
     constexpr size_t lds = tiles > red ? tiles : red;
     static_assert(lds <= 160 * 1024, "tile does not fit the 160 KB of LDS");
-    if (lds > 48 * 1024) {  // more dynamic LDS than the default limit: opt in once per instantiation
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_kernel<WM, WN, TM, TN, KS, KW>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)once;
+    if (lds > 48 * 1024) {  // more dynamic LDS than the default limit: opt in once per instantiation and device
+        static PerDeviceOnce once;
+        once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_kernel<WM, WN, TM, TN, KS, KW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; });
     }
     hipLaunchKernelGGL((conv_frag_kernel<WM, WN, TM, TN, KS, KW>), grid, dim3(64 * WM * WN * KW), lds, stream, s);
 }
@@ -399,9 +398,8 @@ static void launch_frag_chain_instance(const StreamArgs &s1, const StreamArgs &s
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = sizeof(float) * 2 * (KS * BM * 16 + KS * 16 * BN);
     if (lds > 48 * 1024) {
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_chain_kernel<WM, WN, TM, TN, KS>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)once;
+        static PerDeviceOnce once;
+        once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_frag_chain_kernel<WM, WN, TM, TN, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess; });
     }
     hipLaunchKernelGGL((conv_frag_chain_kernel<WM, WN, TM, TN, KS>), grid, dim3(64 * WM * WN), lds, stream, s1, s2);
 }

@@ -306,14 +306,10 @@ template <int K, int S, int MB1, int MB2, int C1>
 static bool launch_pair_t(const PairArgs &a_in, hipStream_t s)
 {
     using G = PairGeom<K, S, MB1, MB2, C1>;
-    static bool configured = false;
-    if (!configured) {
-        if (G::lds_bytes > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pair_kernel<K, S, MB1, MB2, C1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)G::lds_bytes) != hipSuccess)
-            return false;
-        configured = true;
-    }
+    static PerDeviceOnce once;
+    if (G::lds_bytes > 64 * 1024 &&
+        !once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_pair_kernel<K, S, MB1, MB2, C1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::lds_bytes) == hipSuccess; }))
+        return false;
     PairArgs a = a_in;
     a.steps1 = (a.Cin + C1 - 1) / C1;
     a.steps2 = (a.CM + G::CKS2 - 1) / G::CKS2;

@@ -40,11 +40,15 @@ __device__ __forceinline__ int wdiv(int n, unsigned magic) { return magic ? (int
 // 32-lane LDS access group on the odd banks -- conflict free for TX = 16 and TX = 8.
 constexpr int WINO_PWL = 40, WINO_NT = 256, WINO_CKS = 4;
 
-template <int TN, int EPT, int OCC>
+// MB: 16-channel blocks per wave (round 4).  The transformed B fragments of a tile block then feed MB MFMAs each, so the 12 VALU
+// instructions and 9 LDS reads of the input transform are spread over twice the matrix work, and half as many workgroups stage the
+// same input patch.
+template <int TN, int EPT, int OCC, int MB>
 __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
 {
     constexpr int NT = WINO_NT, CKS = WINO_CKS, PWL = WINO_PWL;
-    constexpr int ASZ = 4 * 4 * CKS * 16;  // floats of one weight tile: [class][tap][k][16 channels]
+    constexpr int ASZ1 = 4 * 4 * CKS * 16;  // floats of one 16-channel weight tile: [class][tap][k][16 channels]
+    constexpr int ASZ = MB * ASZ1;          // [mb][class][tap][k][16]
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;               // [2][ASZ]
     const int patch_floats = a.G * CKS * a.PS;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     const int zs = blockIdx.z;
     unsigned bx, by;
     xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
-    const int m0 = by * 16;
+    const int m0 = by * (16 * MB);
     const int tyg = wdiv((int)bx, a.m_tilesx);
     const int tx = (int)bx - tyg * a.tiles_x;
     const int tgrp = wdiv(tyg, a.m_tilesy);
@@ -124,15 +128,17 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
 #pragma unroll
     for (int i = 0; i < EPT; ++i) asm volatile("" : "+v"(lds_p[1][i]));
 
-    floatx4 acc[TN][9];
+    floatx4 acc[MB][TN][9];
 #pragma unroll
-    for (int tb = 0; tb < TN; ++tb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int q = 0; q < 9; ++q) acc[tb][q] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) acc[mb][tb][q] = floatx4{0.0f, 0.0f, 0.0f, 0.0f};
 
     float pregA[EPT], pregB[EPT];
-    floatx4 aregA, aregB;
-    auto load_tiles = [&](float (&preg)[EPT], floatx4 &areg, int step) {
+    floatx4 aregA[MB], aregB[MB];
+    auto load_tiles = [&](float (&preg)[EPT], floatx4 (&areg)[MB], int step) {
         const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * a.H * a.W), 0, NREC, 0x00020000);
         const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp + (long)step * CKS * a.Mpad), 0, NREC, 0x00020000);
         if (mask_last && step == a.nsteps_total - 1) {   // (uniform) channels past Cin read as zero
@@ -143,12 +149,14 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
 #pragma unroll
             for (int i = 0; i < EPT; ++i) preg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i], 0, 0));
         }
-        areg = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff, 0, 0));
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) areg[mb] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, aoff + 64 * mb, 0, 0));
     };
-    auto store_tiles = [&](const float (&preg)[EPT], const floatx4 &areg, int buf) {
+    auto store_tiles = [&](const float (&preg)[EPT], const floatx4 (&areg)[MB], int buf) {
 #pragma unroll
         for (int i = 0; i < EPT; ++i) smem[lds_p[buf][i]] = preg[i];
-        *reinterpret_cast<floatx4 *>(As + buf * ASZ + tid * 4) = areg;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) *reinterpret_cast<floatx4 *>(As + buf * ASZ + mb * ASZ1 + tid * 4) = areg[mb];
     };
     // ---- K loop.  One K-step = 4 input channels = one MFMA K group; global loads run two K-steps ahead (two register sets).
     // The one barrier of a step sits in front of the LAST tile block's MFMAs:
@@ -168,16 +176,23 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
         load_tiles(pregA, aregA, phys(2));
     }
     __syncthreads();
-    float U[9], gn[4], d[9];
+    float U[MB][9], gn[MB][4], d[9];
     auto read_taps = [&](int buf) {
         const float *A = smem + ra[buf];
-        gn[0] = A[0]; gn[1] = A[64]; gn[2] = A[128]; gn[3] = A[192];   // taps (ty,tx) = (0,0), (0,1), (1,0), (1,1)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {   // taps (ty,tx) = (0,0), (0,1), (1,0), (1,1)
+            gn[mb][0] = A[mb * ASZ1 + 0]; gn[mb][1] = A[mb * ASZ1 + 64]; gn[mb][2] = A[mb * ASZ1 + 128]; gn[mb][3] = A[mb * ASZ1 + 192];
+        }
     };
     auto make_u = [&]() {
-        const float s23 = gn[2] + gn[3], s13 = gn[1] + gn[3], s02 = gn[0] + gn[2], s01 = gn[0] + gn[1];
-        U[0] = gn[3]; U[1] = s23;       U[2] = gn[2];
-        U[3] = s13;   U[4] = s01 + s23; U[5] = s02;
-        U[6] = gn[1]; U[7] = s01;       U[8] = gn[0];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const float *g = gn[mb];
+            const float s23 = g[2] + g[3], s13 = g[1] + g[3], s02 = g[0] + g[2], s01 = g[0] + g[1];
+            U[mb][0] = g[3]; U[mb][1] = s23;       U[mb][2] = g[2];
+            U[mb][3] = s13;  U[mb][4] = s01 + s23; U[mb][5] = s02;
+            U[mb][6] = g[1]; U[mb][7] = s01;       U[mb][8] = g[0];
+        }
     };
     auto read_d = [&](int buf, int tb) {
         const float *p = smem + rb[buf][tb];
@@ -199,7 +214,9 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     };
     auto mfmas = [&](int tb) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) acc[tb][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[q], b[q], acc[tb][q], 0, 0, 0);
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb][tb][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(U[mb][q], b[q], acc[mb][tb][q], 0, 0, 0);
     };
     auto head = [&](int buf) {   // blocks 0 .. TN-2, and the transform of the last block
 #pragma unroll
@@ -247,7 +264,10 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     // output row as 16 bytes, 16 lanes = 256 contiguous bytes (4-byte stores of every second pixel made the big maps store bound).
     const bool wide = a.ksplit == 1 && (a.W & 1) == 0;
     float *X = smem;   // [wave][tb][e][ib][64 lanes]
-    if (wide) __syncthreads();   // every wave is done reading the tile buffers
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+    const int mc = m0 + 16 * mb;   // first output channel of this block
+    if (wide) __syncthreads();   // every wave is done reading the tile buffers (mb = 0) / the previous block's exchange
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
         const int q = tb * 16 + l15;
@@ -267,7 +287,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
                 for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib)
-                        o[ia][ib] = (acc[tb][ia * 3 + ib][e] + acc[tb][ia * 3 + ib + 1][e]) + (acc[tb][(ia + 1) * 3 + ib][e] + acc[tb][(ia + 1) * 3 + ib + 1][e]);
+                        o[ia][ib] = (acc[mb][tb][ia * 3 + ib][e] + acc[mb][tb][ia * 3 + ib + 1][e]) + (acc[mb][tb][(ia + 1) * 3 + ib][e] + acc[mb][tb][(ia + 1) * 3 + ib + 1][e]);
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) {
                     keep[e][ib] = px ? o[1][ib] : o[0][ib];
@@ -276,19 +296,19 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
             }
             // stash the kept values in the accumulator registers this block no longer needs
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc[tb][0][e] = keep[e][0]; acc[tb][1][e] = keep[e][1]; }
+            for (int e = 0; e < 4; ++e) { acc[mb][tb][0][e] = keep[e][0]; acc[mb][tb][1][e] = keep[e][1]; }
             continue;
         }
         if (!tv) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int co = m0 + 4 * lk + e;
+            const int co = mc + 4 * lk + e;
             float o[2][2];
 #pragma unroll
             for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib)
-                    o[ia][ib] = (acc[tb][ia * 3 + ib][e] + acc[tb][ia * 3 + ib + 1][e]) + (acc[tb][(ia + 1) * 3 + ib][e] + acc[tb][(ia + 1) * 3 + ib + 1][e]);
+                    o[ia][ib] = (acc[mb][tb][ia * 3 + ib][e] + acc[mb][tb][ia * 3 + ib + 1][e]) + (acc[mb][tb][(ia + 1) * 3 + ib][e] + acc[mb][tb][(ia + 1) * 3 + ib + 1][e]);
             if (a.ksplit > 1) {   // partial sums in output space, layout [cls][slice][Mpad][P] (conv_splitk_reduce finishes)
                 float *__restrict__ ws = a.ws + (((long)wave * a.ksplit + zs) * a.Mpad + co) * P + ((long)n * a.H + y0) * a.W + x0;
 #pragma unroll
@@ -310,11 +330,11 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
             }
         }
     }
-    if (!wide) return;
+    if (!wide) continue;
     __syncthreads();
     // stores through a buffer resource on this workgroup's corner of the output: uniform 64-bit base, one 32-bit offset per lane;
     // padding lanes, rows past the image and channels past Cout carry an out-of-range offset (dropped by the hardware)
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n0 * a.out_n_stride + (long)m0 * plane, 0, 0x40000000, 0x00020000);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n0 * a.out_n_stride + (long)mc * plane, 0, 0x40000000, 0x00020000);
     const int plane4 = 4 * (int)plane;
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
@@ -328,9 +348,9 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
         const int toff = tv ? 4 * (g * (int)a.out_n_stride + (2 * ya + py) * a.Wo + 2 * x0) + 4 * lk * plane4 : 0x7ffffff0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float b = a.bias[m0 + 4 * lk + e];   // (padded to Mpad)
+            const float b = a.bias[mc + 4 * lk + e];   // (padded to Mpad)
             const float p0 = X[((((wave ^ 1) * TN + tb) * 4 + e) * 2 + 0) * 64 + lane], p1 = X[((((wave ^ 1) * TN + tb) * 4 + e) * 2 + 1) * 64 + lane];
-            const float m0v = acc[tb][0][e], m1v = acc[tb][1][e];
+            const float m0v = acc[mb][tb][0][e], m1v = acc[mb][tb][1][e];
             floatx4 v = px ? floatx4{p0, m0v, p1, m1v} : floatx4{m0v, p0, m1v, p1};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -338,8 +358,9 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
                 if (a.act) v[i] = fmaxf(v[i], 0.1f * v[i]);   // == (v >= 0 ? v : 0.1 v)
             }
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, (tv && m0 + 4 * lk + e < a.Cout) ? toff + e * plane4 : 0x7ffffff0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, (tv && mc + 4 * lk + e < a.Cout) ? toff + e * plane4 : 0x7ffffff0, 0, 0);
         }
+    }
     }
 }
 
@@ -680,11 +701,13 @@ __global__ __launch_bounds__(256) void wino1d_repack_kernel(float *__restrict__ 
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
-int wino_variant_tn(int v) { return v == 0 ? 2 : (v == 1 ? 4 : (v == 2 ? 3 : 1)); }
+// variants 0..3: one 16-channel block per wave, 32 / 64 / 48 / 16 tiles per workgroup; 4, 5: two blocks per wave (32 channels), 16 / 32 tiles
+int wino_variant_tn(int v) { return v == 0 ? 2 : (v == 1 ? 4 : (v == 2 ? 3 : (v == 5 ? 2 : 1))); }
+int wino_variant_mb(int v) { return v >= 4 ? 2 : 1; }
 
-size_t wino_lds_bytes(const WinoArgs &a, int tn)
+size_t wino_lds_bytes(const WinoArgs &a, int tn, int mb)
 {
-    const size_t kloop = 2ul * 4 * 4 * WINO_CKS * 16 + 2ul * a.G * WINO_CKS * a.PS + WINO_NT;
+    const size_t kloop = 2ul * mb * 4 * 4 * WINO_CKS * 16 + 2ul * a.G * WINO_CKS * a.PS + WINO_NT;
     const size_t exchange = 4ul * tn * 4 * 2 * 64;   // epilogue: [wave][tb][e][ib][lane]
     return sizeof(float) * (kloop > exchange ? kloop : exchange);
 }
@@ -693,6 +716,7 @@ size_t wino_lds_bytes(const WinoArgs &a, int tn)
 bool wino_plan_geometry(WinoArgs &a, int variant, int n)
 {
     const int ntile = 16 * wino_variant_tn(variant);
+    if (a.Mpad % (16 * wino_variant_mb(variant))) return false;
     const int ity = (a.H + 1) / 2, itx = (a.W + 1) / 2;   // tiles of one image
     double best = 1e30;
     bool ok = false;
@@ -719,35 +743,41 @@ bool wino_plan_geometry(WinoArgs &a, int variant, int n)
     auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
     a.m_plane = magic(a.PH * a.PW); a.m_pw = magic(a.PW); a.m_tytx = magic(a.TY * a.TX); a.m_tx = magic(a.TX);
     a.m_tilesx = magic(a.tiles_x); a.m_tilesy = magic(a.tiles_y);
-    return wino_lds_bytes(a, wino_variant_tn(variant)) <= 64 * 1024;
+    return wino_lds_bytes(a, wino_variant_tn(variant), wino_variant_mb(variant)) <= 64 * 1024;
 }
 
-long wino_workgroups(const WinoArgs &a)
+long wino_workgroups(const WinoArgs &a, int variant)
 {
-    return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * (a.Mpad / 16);
+    return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * (a.Mpad / (16 * wino_variant_mb(variant)));
 }
 
-template <int TN, int OCC>
+template <int TN, int OCC, int MB>
 static void launch_wino_ept(const WinoArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
     const long elems = (long)a.G * WINO_CKS * a.PH * a.PW;
     const int per_thread = (int)((elems + WINO_NT - 1) / WINO_NT);
-    if (per_thread <= 2) hipLaunchKernelGGL((wino_deconv_kernel<TN, 2, OCC>), grid, dim3(WINO_NT), lds, s, a);
-    else if (per_thread <= 4) hipLaunchKernelGGL((wino_deconv_kernel<TN, 4, OCC>), grid, dim3(WINO_NT), lds, s, a);
-    else if (per_thread <= 6) hipLaunchKernelGGL((wino_deconv_kernel<TN, 6, OCC>), grid, dim3(WINO_NT), lds, s, a);
-    else hipLaunchKernelGGL((wino_deconv_kernel<TN, 8, (OCC > 1 && TN != 3 ? OCC - 1 : OCC)>), grid, dim3(WINO_NT), lds, s, a);   // 8 staged elements per thread: one wave per SIMD less, no spills
+    if (per_thread <= 2) hipLaunchKernelGGL((wino_deconv_kernel<TN, 2, OCC, MB>), grid, dim3(WINO_NT), lds, s, a);
+    else if (per_thread <= 4) hipLaunchKernelGGL((wino_deconv_kernel<TN, 4, OCC, MB>), grid, dim3(WINO_NT), lds, s, a);
+    else if (per_thread <= 6) hipLaunchKernelGGL((wino_deconv_kernel<TN, 6, (MB == 2 && TN == 1 ? OCC - 1 : OCC), MB>), grid, dim3(WINO_NT), lds, s, a);   // (two spilled registers at 3 waves per SIMD)
+    else hipLaunchKernelGGL((wino_deconv_kernel<TN, 8, (OCC > 1 && TN != 3 ? OCC - 1 : OCC), MB>), grid, dim3(WINO_NT), lds, s, a);   // 8 staged elements per thread: one wave per SIMD less, no spills
 }
 
 void launch_wino_deconv(const WinoArgs &a, int variant, hipStream_t stream)
 {
     const int groups = (a.N + a.G - 1) / a.G;
-    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / 16), (unsigned)a.ksplit);
-    const size_t lds = wino_lds_bytes(a, wino_variant_tn(variant));
-    switch (wino_variant_tn(variant)) {
-        case 2: launch_wino_ept<2, 3>(a, grid, lds, stream); break;
-        case 3: launch_wino_ept<3, 2>(a, grid, lds, stream); break;
-        case 1: launch_wino_ept<1, 4>(a, grid, lds, stream); break;
-        default: launch_wino_ept<4, 2>(a, grid, lds, stream); break;
+    const int tn = wino_variant_tn(variant), mb = wino_variant_mb(variant);
+    dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / (16 * mb)), (unsigned)a.ksplit);
+    const size_t lds = wino_lds_bytes(a, tn, mb);
+    if (mb == 2) {
+        if (tn == 1) launch_wino_ept<1, 3, 2>(a, grid, lds, stream);
+        else launch_wino_ept<2, 2, 2>(a, grid, lds, stream);
+        return;
+    }
+    switch (tn) {
+        case 2: launch_wino_ept<2, 3, 1>(a, grid, lds, stream); break;
+        case 3: launch_wino_ept<3, 2, 1>(a, grid, lds, stream); break;
+        case 1: launch_wino_ept<1, 4, 1>(a, grid, lds, stream); break;
+        default: launch_wino_ept<4, 2, 1>(a, grid, lds, stream); break;
     }
 }
 

@@ -719,7 +719,7 @@ bool run_wino(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStr
     if (ksplit > w.nsteps_total) ksplit = w.nsteps_total;
     w.ksplit = ksplit;
     launch_wino_deconv(w, variant, s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino_deconv<16x%d>%s", 16 * wino_variant_tn(variant), split_suffix(ksplit));
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino_deconv<%dx%d>%s", 16 * wino_variant_mb(variant), 16 * wino_variant_tn(variant), split_suffix(ksplit));
     g_last_kernel = g_kernel_tag;
     if (ksplit > 1) {
         ConvArgs r = a;
@@ -1173,7 +1173,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
             WinoArgs w;
             w.N = n; w.H = a.H; w.W = a.W; w.Mpad = L->Mpad;
             if (!wino_plan_geometry(w, v, n)) continue;
-            const long wgs = wino_workgroups(w);
+            const long wgs = wino_workgroups(w, v);
             for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
                 if (ks > 1 && (ks > nsteps / 8 || wgs * ks > 4096 || (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
                 if (wgs * ks < 96) continue;

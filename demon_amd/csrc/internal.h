@@ -255,10 +255,11 @@ struct WinoArgs {
     int xcd;
     unsigned m_plane, m_pw, m_tytx, m_tx, m_tilesx, m_tilesy;   // magic numbers for the prologue divisions
 };
-constexpr int WINO_VARIANTS = 4;   // tiles per workgroup: 32, 64, 48, 16
+constexpr int WINO_VARIANTS = 6;   // tiles per workgroup: 32, 64, 48, 16 (16 output channels); 16, 32 (32 output channels)
 int wino_variant_tn(int v);
+int wino_variant_mb(int v);
 bool wino_plan_geometry(WinoArgs &a, int variant, int n);
-long wino_workgroups(const WinoArgs &a);
+long wino_workgroups(const WinoArgs &a, int variant);
 void launch_wino_deconv(const WinoArgs &a, int variant, hipStream_t stream);
 
 // ---- 1-D minimal filtering for the k x 1 / 1 x k convs (conv_wino.hip, wino1d_tables.h) -------------------------------------------------

@@ -53,9 +53,9 @@ def kernel_tag(name):
             if p == params:
                 return "conv_frag<%dx%d,v%d>" % (32 * tm * wm, 32 * tn * wn, v)
         return "conv_frag<%dx%d,?>" % (32 * tm * wm, 32 * tn * wn)
-    m = re.search(r"wino_deconv_kernel<(\d+)", name)
-    if m:
-        return "wino_deconv<16x%d>" % (16 * int(m.group(1)))
+    m = re.search(r"wino_deconv_kernel<(\d+), \d+, \d+, (\d+)", name)
+    if m:   # <tile blocks, staged elements per thread, waves per SIMD, 16-channel blocks per wave>
+        return "wino_deconv<%dx%d>" % (16 * int(m.group(2)), 16 * int(m.group(1)))
     m = re.search(r"wino1d_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
     if m:   # (the 3 x 3 layers, tag "t3x3", run the 3-tap instance: the template name cannot tell them apart)
         kind, axis, wm, wn, tn, kg = map(int, m.groups())
@@ -103,7 +103,7 @@ def rocprof_kernel_name(tag):
     if fam == "conv_patch" and len(dims) == 2:
         return "demon::conv_patch_kernel<%s, ...> (%sx%s tile, %s taps)" % (dims[0], dims[0], dims[1], rest.rstrip(">").split(",t")[-1])
     if fam == "wino_deconv" and len(dims) == 2:
-        return "demon::wino_deconv_kernel<%d, ...> (16 channels x %s tiles per workgroup)" % (int(dims[1]) // 16, dims[1])
+        return "demon::wino_deconv_kernel<%d, ..., %d> (%s channels x %s tiles per workgroup)" % (int(dims[1]) // 16, int(dims[0]) // 16, dims[0], dims[1])
     if fam == "wino4":
         return "demon::wino4_kernel<...> (%s)" % rest.rstrip(">")
     if fam == "wino3rows":

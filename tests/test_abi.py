@@ -127,7 +127,8 @@ def test_kernel_names_round_trip():
         "void demon::conv_patch_kernel<64, 2, 2, 1, 1, 4, 4, 2>(demon::PatchArgs)": "conv_patch<64x64,t4>",
         "void demon::conv_mfma_kernel<128, 32, 4, 1, false>(demon::ConvArgs)": "conv_mfma<128x32>",
         "void demon::deconv4_kernel<32, 1, 4, 4>(demon::PatchArgs)": "deconv4<32x128>",
-        "void demon::wino_deconv_kernel<2, 4, 3>(demon::WinoArgs)": "wino_deconv<16x32>",
+        "void demon::wino_deconv_kernel<2, 4, 3, 1>(demon::WinoArgs)": "wino_deconv<16x32>",
+        "void demon::wino_deconv_kernel<1, 2, 3, 2>(demon::WinoArgs)": "wino_deconv<32x16>",
         "void demon::wino1d_kernel<1, 0, 2, 2, 2, 1, false>(demon::Wino1Args)": "wino1d<t5,v0>",
         "void demon::wino1d_kernel<0, 1, 4, 1, 4, 2, false>(demon::Wino1Args)": "wino1d<t3,v5>",
         "void demon::wino1d_kernel<0, 0, 4, 1, 3, 4, false>(demon::Wino1Args)": "wino1d<t3,v8>",

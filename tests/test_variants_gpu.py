@@ -141,12 +141,12 @@ def test_minimal_filtering_deconv(gpu_ctx, shape):
     try:
         os.environ["DEMON_FORCE_PLAN"] = "1,8,0"
         direct = gpu_ctx.deconv4x4s2(x, w, b, lrelu=True)
-        for v in range(4):
+        for v in range(6):   # 4, 5: two 16-channel blocks per wave (the packed weights are padded to a multiple of 32 channels)
             for ks in (1, 2, 5):
                 os.environ["DEMON_FORCE_PLAN"] = "8,%d,%d" % (v, ks)
                 got = gpu_ctx.deconv4x4s2(x, w, b, lrelu=True)
                 tag = gpu_ctx.last_kernel()
-                assert tag.startswith("wino_deconv<16x%d>" % (32, 64, 48, 16)[v]), tag
+                assert tag.startswith("wino_deconv<%dx%d>" % ((16, 32), (16, 64), (16, 48), (16, 16), (32, 16), (32, 32))[v]), tag
                 assert ("+splitk" in tag) == (ks > 1), tag
                 err = rel_l1(got, want)
                 assert err < 1e-5, "variant %d split %d: rel L1 %.3e" % (v, ks, err)
