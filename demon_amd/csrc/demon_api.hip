@@ -1834,10 +1834,14 @@ void prepare_stream_weights(demon_ctx *c)
     for (auto &L : c->layers) refresh_stream_weights(L.get(), c->stream);
 }
 
+// between demon_release_streams and demon_acquire_streams a context has no stream: nothing may fall onto the null stream
+const char *const kNoStream = "the context gave its HIP streams back (demon_release_streams); call demon_acquire_streams first";
+
 int check_batch(demon_ctx *c, int n)
 {
     if (!c) return DEMON_ERR_INVALID;
     if (n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "batch size out of range [1, max_batch]");
+    if (!c->stream) return fail(c, DEMON_ERR_NOT_READY, kNoStream);
     std::string missing;
     if (!weights_ready(c, &missing)) return fail(c, DEMON_ERR_NOT_READY, "weights not set for layer " + missing);
     hipSetDevice(c->device);
@@ -1848,6 +1852,7 @@ int check_batch(demon_ctx *c, int n)
 int h2d(demon_ctx *c, const View &v, const float *host, int n)
 {
     if (!host) return fail(c, DEMON_ERR_INVALID, "null input pointer");
+    if (!c->stream) return fail(c, DEMON_ERR_NOT_READY, kNoStream);
     const size_t row = sizeof(float) * (size_t)v.C * v.H * v.W;
     HIP_TRY(c, hipMemcpy2DAsync(v.ptr(), sizeof(float) * v.n_stride(), host, row, row, n, hipMemcpyHostToDevice, c->stream));
     return DEMON_OK;
@@ -1856,6 +1861,7 @@ int h2d(demon_ctx *c, const View &v, const float *host, int n)
 int d2h(demon_ctx *c, float *host, const View &v, int n)
 {
     if (!host) return DEMON_OK;
+    if (!c->stream) return fail(c, DEMON_ERR_NOT_READY, kNoStream);
     const size_t row = sizeof(float) * (size_t)v.C * v.H * v.W;
     HIP_TRY(c, hipMemcpy2DAsync(host, row, v.ptr(), sizeof(float) * v.n_stride(), row, n, hipMemcpyDeviceToHost, c->stream));
     return DEMON_OK;
@@ -2222,6 +2228,7 @@ int demon_broadcast_weights(demon_ctx *c, void *nccl_comm, int root, int rank)
 {
     if (!c || !nccl_comm) return fail(c, DEMON_ERR_INVALID, "null argument");
     if (!c->w_slab) return fail(c, DEMON_ERR_INVALID, "context has no networks (demon_create_ops)");
+    if (!c->stream) return fail(c, DEMON_ERR_NOT_READY, kNoStream);
     RcclApi &r = rccl();
     if (!r.err.empty()) return rccl_fail(c, "rccl", 0);
     std::string missing;
@@ -2266,6 +2273,7 @@ int demon_copy_weights_from(demon_ctx *dst, const demon_ctx *src)
     if (!dst || !src) return fail(dst, DEMON_ERR_INVALID, "null argument");
     if (!dst->w_slab || !src->w_slab) return fail(dst, DEMON_ERR_INVALID, "context has no networks (demon_create_ops)");
     if (slab_layout_hash(dst) != slab_layout_hash(src)) return fail(dst, DEMON_ERR_INVALID, "weight slab layouts differ (other model variant or image size)");
+    if (!dst->stream || !src->stream) return fail(dst, DEMON_ERR_NOT_READY, kNoStream);
     std::string missing;
     if (!weights_ready(const_cast<demon_ctx *>(src), &missing)) return fail(dst, DEMON_ERR_NOT_READY, "source context: weights not set for layer " + missing);
     hipSetDevice(src->device);
@@ -2497,7 +2505,7 @@ int demon_synchronize(demon_ctx *c)
 {
     if (!c) return DEMON_ERR_INVALID;
     hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));   // (no stream between release and acquire: nothing is in flight)
     return DEMON_OK;
 }
 
@@ -2697,6 +2705,7 @@ int demon_profile_full(demon_ctx *c, int n, int iterations, int repeats, demon_l
 // ---- op-level entry points -----------------------------------------------------------------------------
 #define OP_PROLOGUE(c)                                   \
     if (!(c)) return DEMON_ERR_INVALID;                  \
+    if (!(c)->stream) return fail(c, DEMON_ERR_NOT_READY, kNoStream); \
     hipSetDevice((c)->device);                           \
     TmpDev tmp;
 

@@ -146,7 +146,8 @@ int demon_synchronize(demon_ctx *ctx);
  * depends on every stream alive in the process, and two busy streams on one queue serialise.  A group of contexts that measures a
  * poor mapping (demon_amd/lanes.py: LaneGroup.calibrate) releases all its streams, optionally creates placeholder streams
  * (demon_create_ops contexts), and acquires new ones context by context.  Nothing may be in flight; captured graphs stay valid.
- * Between release and acquire the context must not be used.                                                              */
+ * Between release and acquire the context must not be used: every entry point that would enqueue work returns
+ * DEMON_ERR_NOT_READY (nothing falls onto the null stream); demon_synchronize, demon_set_weight*, demon_plan_* still work.   */
 int demon_release_streams(demon_ctx *ctx);
 int demon_acquire_streams(demon_ctx *ctx);
 int demon_download_outputs(demon_ctx *ctx, int n, const demon_outputs *out, float *predict_depth0);

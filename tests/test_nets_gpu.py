@@ -540,3 +540,29 @@ def test_lane_group_calibration_keeps_results(synth_weights):
             np.testing.assert_array_equal(before[0][k], want[k], err_msg=k)
     finally:
         group.close()
+
+
+def test_released_streams_refuse_work(synth_weights):
+    """demon_release_streams / demon_acquire_streams (include/demon_hip.h): between the two a context has no HIP stream; every entry
+    point that would enqueue work must refuse (DEMON_ERR_NOT_READY) instead of falling onto the null stream, and after acquiring
+    new streams the context computes what it computed before (its captured hipGraph survives)."""
+    from demon_amd import DemonContext
+    from demon_amd.engine import DemonError
+    n = 1
+    ctx = DemonContext(0, n, 192, 256)
+    try:
+        ctx.set_weights(synth_weights)
+        pair, img2_2 = make_inputs(n, seed=77)
+        want = ctx.full(pair, img2_2, iterations=1)
+        ctx.release_streams()
+        ctx.synchronize()                                   # nothing in flight: fine
+        for call in (lambda: ctx.run_full(n, 1), lambda: ctx.upload_inputs(pair, img2_2), lambda: ctx.download_outputs(n),
+                     lambda: ctx.leaky_relu(np.ones((4,), np.float32))):
+            with pytest.raises(DemonError, match="demon_acquire_streams"):
+                call()
+        ctx.acquire_streams()
+        got = ctx.full(pair, img2_2, iterations=1)
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    finally:
+        ctx.close()
