@@ -356,6 +356,8 @@ def main():
                     return 9.0 / 16.0            # F(2,2) x F(2,2) per sub-pixel class
                 if tag.startswith("wino3rows<f4"):
                     return 6.0 / 12.0            # F(4,3) row filters
+                if tag.startswith("wino3rows<s2"):
+                    return 9.0 / 12.0            # stride 2: polyphase F(4,2) + F(4,1) row filters
                 if tag.startswith("wino4<t3"):
                     return 6.0 / 12.0            # F(4,3)
                 if tag.startswith("wino4<t5"):

@@ -19,6 +19,11 @@
 // kernel row instead of 12 (F(2,3): 8) -- 0.5 x the direct convolution's multiply-adds; interpolation points 0, +-1, +-2, infinity
 // (wino1d_tables.h, generated and checked in exact rationals; fp32 error 2 x a direct fp32 sum at K = 128, tools/gen_wino1d.py).
 // Its weights U43[ky][e][ci][co] (6 planes per kernel row) live in a buffer of their own (wino3_repack43_kernel).
+// Stride-2 form (FORM 2; the refinement net's conv1 / conv2, blocks_original.py:484-511): output row r reads the input rows 2r - 1, 2r,
+// 2r + 1, so a wave's TN output rows share 2 TN + 1 transformed input rows (the odd ones feed two output rows); along x the polyphase
+// split gives the even / odd input samples the even / odd taps as stride-1 filters: four outputs from a window of nine pixels with
+// F(4,2) + F(4,1) = 9 products per kernel row instead of 12 (0.75 x the direct convolution's multiply-adds, transforms of the even
+// samples only).  Its weights U[ky][e][ci][co] (9 planes per kernel row) come from the same repack kernel.
 #include <type_traits>
 
 #include "internal.h"
@@ -39,14 +44,16 @@ struct Rows23 {   // F(2,3) along x: the 3-tap stride-1 kind of wino1d_tables.h 
 };
 
 // WM x WN waves: WM 16-channel blocks x WN blocks of 16 tile columns; TN output rows per wave; KG K groups (of 4 channels) per barrier;
-// F4: tiles of four pixels (F(4,3)) instead of two (F(2,3))
-template <int WM, int WN, int TN, int KG, bool MASK, bool F4>
+// FORM 0: stride 1, tiles of two pixels (F(2,3)); 1: stride 1, tiles of four pixels (F(4,3)); 2: stride 2, tiles of four pixels (F(4,2) + F(4,1))
+template <int WM, int WN, int TN, int KG, bool MASK, int FORM>
 __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a)   // (2 waves per SIMD: 256 registers; 3 spills -- the F(4,3) shapes therefore hold 2 or 3 rows per wave: 24 accumulator registers per row)
 {
-    using K = typename std::conditional<F4, Wino43, Rows23>::type;
+    using K = typename std::conditional<FORM == 2, Wino4K3S2, typename std::conditional<FORM == 1, Wino43, Rows23>::type>::type;
+    constexpr bool F4 = FORM == 1, S2 = FORM == 2;
+    constexpr int SY = S2 ? 2 : 1;   // stride (rows and columns)
     constexpr int NUV = K::NUV, WIN = K::WIN, OUT = K::OUT, NT = 64 * WM * WN, CKS = 4 * KG;
-    constexpr int PWD = F4 ? 6 : 6;   // floats a unit loads: F(2,3) three 8-byte vectors around its window, F(4,3) exactly its six pixels
-    constexpr int BM = 16 * WM, TCOLS = 16 * WN, RIN = TN + 2;
+    constexpr int PWD = S2 ? 9 : 6;   // floats a unit loads: F(2,3) three 8-byte vectors around its window, F(4,3) exactly its six pixels, stride 2 its nine
+    constexpr int BM = 16 * WM, TCOLS = 16 * WN, RIN = SY * (TN - 1) + 3;
     constexpr int SLOTS = RIN * TCOLS;                         // (input row, tile column) slots per (e, channel)
     constexpr int TP = SLOTS + ((SLOTS & 31) ? 0 : 16);        // pitch: the k = 0 / 1 halves of a 32-lane LDS access on different banks
     constexpr int NUNIT = SLOTS * CKS;                         // staging units (channel, slot) per K-step
@@ -84,10 +91,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
         const bool uv = NUNIT % NT == 0 || w < NUNIT;
         const int k = uv ? w / SLOTS : 0, slot = uv ? w - k * SLOTS : 0;
         const int j = slot / TCOLS, t = slot - j * TCOLS;
-        const int gy = r0 - 1 + j, c = c0 + t;
+        const int gy = SY * r0 - 1 + j, c = c0 + t;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            const int gx = F4 ? (e == 0 ? 4 * c - 1 : (e == 1 ? 4 * c : 4 * c + 4)) : 2 * (c - 1 + e);
+            // stride 2: the window is the pixel 8 c - 1 and the 16-byte vectors [8 c, 8 c + 4), [8 c + 4, 8 c + 8)
+            const int gx = S2 ? (e == 0 ? 8 * c - 1 : (e == 1 ? 8 * c : 8 * c + 4)) : (F4 ? (e == 0 ? 4 * c - 1 : (e == 1 ? 4 * c : 4 * c + 4)) : 2 * (c - 1 + e));
             const bool ok = uv & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
             goff[i][e] = ok ? 4 * (k * HW + gy * a.W + gx) : OOB;
         }
@@ -134,7 +142,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
 #pragma unroll
             for (int i = 0; i < UNITS; ++i) {
                 const int dead = (LAST && !((lastmask >> i) & 1u)) ? OOB : 0;   // (or-ed into the offsets: OOB covers every bit of a valid offset)
-                if constexpr (F4) {
+                if constexpr (S2) {
+                    preg[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][0] | dead, 0, 0));
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, goff[i][1 + h] | dead, 0, 0));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) preg[i][1 + 4 * h + j] = v[j];
+                    }
+                } else if constexpr (F4) {
                     preg[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prsrc, goff[i][0] | dead, 0, 0));
                     const floatx4 v = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, goff[i][1] | dead, 0, 0));
 #pragma unroll
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
         for (int i = 0; i < UNITS; ++i) {
             float d[WIN], t[NUV];
 #pragma unroll
-            for (int e = 0; e < WIN; ++e) d[e] = preg[i][(F4 ? 0 : 1) + e];   // the window starts one pixel left of the tile
+            for (int e = 0; e < WIN; ++e) d[e] = preg[i][(FORM == 0 ? 1 : 0) + e];   // the window starts one pixel left of the tile
             K::input(d, t);
             float *T = smem + tw[buf][i];
             if constexpr (NUNIT % NT == 0) {
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int tb = 0; tb < TN; ++tb)
-                    acc[tb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[it & 1][ky], tf[it & 1][tb + ky], acc[tb][e], 0, 0, 0);
+                    acc[tb][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[it & 1][ky], tf[it & 1][SY * tb + ky], acc[tb][e], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0x16);
         }
     };
@@ -240,8 +256,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
         const int y = r0 + tb;
-        const bool tv = y < a.H && x0 < a.W;
-        const int toff = tv ? 4 * (y * a.W + x0) + (wm * 16 + 4 * lk) * plane4 : OOB;
+        const bool tv = y < a.Ho && x0 < a.Wo;
+        const int toff = tv ? 4 * (y * a.Wo + x0) + (wm * 16 + 4 * lk) * plane4 : OOB;
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
             const int col = wm * 16 + 4 * lk + e4;
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
                 if (a.act) o[j] = fmaxf(o[j], 0.1f * o[j]);
             }
             const int off = (tv && m0 + col < a.Cout) ? toff + e4 * plane4 : OOB;
-            if constexpr (F4) {
+            if constexpr (OUT == 4) {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, floatx4{o[0], o[1], o[2], o[3]}), orsrc, off, 0, 0);
             } else {
@@ -267,7 +283,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     }
 }
 
-// U43[ky][e][ci][co] = sum_t G43[e][t] wp[(ky*3 + t)*Cin + ci][co]; rows ci >= Cin stay zero (the buffer is zero-filled once)
+// U[ky][e][ci][co] = sum_t G[e][t] wp[(ky*3 + t)*Cin + ci][co] (K = Wino43: F(4,3); Wino4K3S2: stride 2); rows ci >= Cin stay zero (the buffer is zero-filled once)
+template <class K>
 __global__ __launch_bounds__(256) void wino3_repack43_kernel(float *__restrict__ wu, const float *__restrict__ wp, int Cin, int Cin4, int Mpad)
 {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -278,30 +295,33 @@ __global__ __launch_bounds__(256) void wino3_repack43_kernel(float *__restrict__
 #pragma unroll
         for (int t = 0; t < 3; ++t) w[t] = wp[((long)(ky * 3 + t) * Cin + ci) * Mpad + co];
 #pragma unroll
-        for (int e = 0; e < Wino43::NUV; ++e) {
+        for (int e = 0; e < K::NUV; ++e) {
             float u = 0.0f;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) u += Wino43::g(e, t) * w[t];
-            wu[(((long)ky * Wino43::NUV + e) * Cin4 + ci) * Mpad + co] = u;
+            for (int t = 0; t < 3; ++t) u += K::g(e, t) * w[t];
+            wu[(((long)ky * K::NUV + e) * Cin4 + ci) * Mpad + co] = u;
         }
     }
 }
 
-void launch_wino3_repack43(float *wu, const float *wp, int Cin, int Cin4, int Mpad, hipStream_t s)
+void launch_wino3_repack43(float *wu, const float *wp, int Cin, int Cin4, int Mpad, int stride, hipStream_t s)
 {
     const long total = (long)Cin * Mpad;
-    hipLaunchKernelGGL(wino3_repack43_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad);
+    if (stride == 2) hipLaunchKernelGGL(wino3_repack43_kernel<Wino4K3S2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad);
+    else hipLaunchKernelGGL(wino3_repack43_kernel<Wino43>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, wu, wp, Cin, Cin4, Mpad);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
-// variants 0 .. 7: F(2,3) tiles of two pixels; 8 .. 15: the same workgroup shapes on F(4,3) tiles of four pixels
+// variants 0 .. 7: F(2,3) tiles of two pixels; 8 .. 15: F(4,3) tiles of four pixels; 16 .. 19: the stride-2 form (tiles of four pixels)
 struct W3Shape { int wm, wn, tn, kg; };
-constexpr int W3_SHAPES = 8;
-static_assert(WINO3_VARIANTS == 2 * W3_SHAPES, "eight workgroup shapes per form");
+constexpr int W3_SHAPES = 8, W3_S2_SHAPES = 4;
+static_assert(WINO3_VARIANTS == 2 * W3_SHAPES + W3_S2_SHAPES, "eight workgroup shapes per stride-1 form, four for stride 2");
 static const W3Shape kW3Shapes[WINO3_VARIANTS] = {{2, 2, 4, 1}, {2, 4, 4, 1}, {4, 1, 4, 1}, {4, 2, 4, 1}, {1, 4, 4, 1}, {1, 4, 2, 2}, {2, 2, 2, 2}, {4, 1, 2, 2},
-                                                  {2, 2, 2, 2}, {4, 1, 2, 2}, {2, 2, 3, 1}, {4, 1, 3, 1}, {1, 4, 2, 1}, {1, 4, 3, 1}, {2, 1, 2, 2}, {4, 2, 3, 1}};
+                                                  {2, 2, 2, 2}, {4, 1, 2, 2}, {2, 2, 3, 1}, {4, 1, 3, 1}, {1, 4, 2, 1}, {1, 4, 3, 1}, {2, 1, 2, 2}, {4, 2, 3, 1},
+                                                  {4, 1, 2, 1}, {2, 2, 2, 1}, {4, 2, 2, 1}, {8, 1, 2, 1}};
 static const W3Shape &w3shape(int v) { return kW3Shapes[v]; }
-bool wino3_variant_f4(int v) { return v >= W3_SHAPES; }
+int wino3_variant_form(int v) { return v < W3_SHAPES ? 0 : (v < 2 * W3_SHAPES ? 1 : 2); }
+bool wino3_variant_f4(int v) { return wino3_variant_form(v) == 1; }
 int wino3_variant_bm(int v) { return 16 * w3shape(v).wm; }
 int wino3_variant_kg(int v) { return w3shape(v).kg; }
 int wino3_variant_rows(int v) { return w3shape(v).tn; }
@@ -310,8 +330,9 @@ int wino3_variant_cols(int v) { return 16 * w3shape(v).wn; }   // tile columns (
 static size_t wino3_lds_bytes(int v)
 {
     const W3Shape s = w3shape(v);
-    const int nuv = wino3_variant_f4(v) ? 6 : 4;
-    const int cks = 4 * s.kg, slots = (s.tn + 2) * 16 * s.wn, tp = slots + ((slots & 31) ? 0 : 16);
+    const int form = wino3_variant_form(v);
+    const int nuv = form == 2 ? 9 : (form == 1 ? 6 : 4), rin = (form == 2 ? 2 : 1) * (s.tn - 1) + 3;
+    const int cks = 4 * s.kg, slots = rin * 16 * s.wn, tp = slots + ((slots & 31) ? 0 : 16);
     return sizeof(float) * (2ul * (3 * nuv * cks * 16 * s.wm + nuv * cks * tp) + 4ul * 64 * s.wm * s.wn);
 }
 
@@ -319,14 +340,17 @@ bool wino3_plan_geometry(Wino3Args &a, int variant)
 {
     if (variant < 0 || variant >= WINO3_VARIANTS) return false;
     const W3Shape s = w3shape(variant);
-    const int out = wino3_variant_f4(variant) ? 4 : 2;                 // pixels per tile
-    if (a.W % out || a.Mpad % (16 * s.wm)) return false;               // windows are read as 8- / 16-byte vectors
+    const int form = wino3_variant_form(variant);
+    const int out = form == 0 ? 2 : 4;                                 // pixels per tile
+    if ((form == 2) != (a.stride == 2)) return false;
+    if (form == 2 ? (a.W % 8 || a.Wo != a.W / 2 || a.Ho != (a.H + 1) / 2) : (a.Wo != a.W || a.Ho != a.H)) return false;
+    if (a.Wo % out || a.Mpad % (16 * s.wm)) return false;              // windows are read as 8- / 16-byte vectors
     if (s.wm == 1 && a.Cout > 16) return false;                        // (one channel block per workgroup is for <= 16 channels)
     if (16 * s.wm > 16 && a.Cout <= 16) return false;
-    if (a.W < 32) return false;                                        // narrower maps stay on the wino1d kernel (its tiles span images)
-    a.rows_y = (a.H + s.tn - 1) / s.tn;
-    a.cols_x = (a.W / out + 16 * s.wn - 1) / (16 * s.wn);
-    if ((double)a.rows_y * s.tn * a.cols_x * 16 * out * s.wn > 2.5 * a.H * a.W) return false;   // mostly empty tile slots: not worth measuring
+    if (a.Wo < 32) return false;                                       // narrower maps stay on the wino1d kernel (its tiles span images)
+    a.rows_y = (a.Ho + s.tn - 1) / s.tn;
+    a.cols_x = (a.Wo / out + 16 * s.wn - 1) / (16 * s.wn);
+    if ((double)a.rows_y * s.tn * a.cols_x * 16 * out * s.wn > 2.5 * a.Ho * a.Wo) return false;   // mostly empty tile slots: not worth measuring
     a.csteps = (a.Cin + 4 * s.kg - 1) / (4 * s.kg);
     auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
     a.m_colsx = magic(a.cols_x);
@@ -339,47 +363,51 @@ long wino3_workgroups(const Wino3Args &a, int variant)
     return (long)a.N * a.rows_y * a.cols_x * ((a.Cout + wino3_variant_bm(variant) - 1) / wino3_variant_bm(variant));
 }
 
-template <int WM, int WN, int TN, int KG, bool MASK, bool F4>
+template <int WM, int WN, int TN, int KG, bool MASK, int FORM>
 static bool launch_w3m(const Wino3Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
     static PerDeviceOnce once;
     if (lds > 48 * 1024 &&
-        !once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3_rows_kernel<WM, WN, TN, KG, MASK, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
+        !once.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&wino3_rows_kernel<WM, WN, TN, KG, MASK, FORM>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }))
         return false;
-    hipLaunchKernelGGL((wino3_rows_kernel<WM, WN, TN, KG, MASK, F4>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((wino3_rows_kernel<WM, WN, TN, KG, MASK, FORM>), grid, dim3(64 * WM * WN), lds, s, a);
     return true;
 }
 
-template <int WM, int WN, int TN, int KG, bool F4>
+template <int WM, int WN, int TN, int KG, int FORM>
 static bool launch_w3(const Wino3Args &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    if (a.Cin % (4 * KG)) return launch_w3m<WM, WN, TN, KG, true, F4>(a, grid, lds, s);
-    return launch_w3m<WM, WN, TN, KG, false, F4>(a, grid, lds, s);
+    if (a.Cin % (4 * KG)) return launch_w3m<WM, WN, TN, KG, true, FORM>(a, grid, lds, s);
+    return launch_w3m<WM, WN, TN, KG, false, FORM>(a, grid, lds, s);
 }
 
-// a.wu: U[ky][e][Cin4][Mpad] with 4 planes per kernel row for variants 0 .. 7, U43 with 6 planes for variants 8 .. 15
+// a.wu: U[ky][e][Cin4][Mpad] with 4 planes per kernel row for variants 0 .. 7, U43 with 6 planes for variants 8 .. 15, 9 planes for 16 .. 19
 bool launch_wino3(const Wino3Args &a, int variant, hipStream_t stream)
 {
     const int bm = wino3_variant_bm(variant);
     dim3 grid((unsigned)(a.N * a.rows_y * a.cols_x), (unsigned)((a.Cout + bm - 1) / bm), 1);
     const size_t lds = wino3_lds_bytes(variant);
     switch (variant) {
-        case 0: return launch_w3<2, 2, 4, 1, false>(a, grid, lds, stream);
-        case 1: return launch_w3<2, 4, 4, 1, false>(a, grid, lds, stream);
-        case 2: return launch_w3<4, 1, 4, 1, false>(a, grid, lds, stream);
-        case 3: return launch_w3<4, 2, 4, 1, false>(a, grid, lds, stream);
-        case 4: return launch_w3<1, 4, 4, 1, false>(a, grid, lds, stream);
-        case 5: return launch_w3<1, 4, 2, 2, false>(a, grid, lds, stream);
-        case 6: return launch_w3<2, 2, 2, 2, false>(a, grid, lds, stream);
-        case 7: return launch_w3<4, 1, 2, 2, false>(a, grid, lds, stream);
-        case 8: return launch_w3<2, 2, 2, 2, true>(a, grid, lds, stream);
-        case 9: return launch_w3<4, 1, 2, 2, true>(a, grid, lds, stream);
-        case 10: return launch_w3<2, 2, 3, 1, true>(a, grid, lds, stream);
-        case 11: return launch_w3<4, 1, 3, 1, true>(a, grid, lds, stream);
-        case 12: return launch_w3<1, 4, 2, 1, true>(a, grid, lds, stream);
-        case 13: return launch_w3<1, 4, 3, 1, true>(a, grid, lds, stream);
-        case 14: return launch_w3<2, 1, 2, 2, true>(a, grid, lds, stream);
-        default: return launch_w3<4, 2, 3, 1, true>(a, grid, lds, stream);
+        case 0: return launch_w3<2, 2, 4, 1, 0>(a, grid, lds, stream);
+        case 1: return launch_w3<2, 4, 4, 1, 0>(a, grid, lds, stream);
+        case 2: return launch_w3<4, 1, 4, 1, 0>(a, grid, lds, stream);
+        case 3: return launch_w3<4, 2, 4, 1, 0>(a, grid, lds, stream);
+        case 4: return launch_w3<1, 4, 4, 1, 0>(a, grid, lds, stream);
+        case 5: return launch_w3<1, 4, 2, 2, 0>(a, grid, lds, stream);
+        case 6: return launch_w3<2, 2, 2, 2, 0>(a, grid, lds, stream);
+        case 7: return launch_w3<4, 1, 2, 2, 0>(a, grid, lds, stream);
+        case 8: return launch_w3<2, 2, 2, 2, 1>(a, grid, lds, stream);
+        case 9: return launch_w3<4, 1, 2, 2, 1>(a, grid, lds, stream);
+        case 10: return launch_w3<2, 2, 3, 1, 1>(a, grid, lds, stream);
+        case 11: return launch_w3<4, 1, 3, 1, 1>(a, grid, lds, stream);
+        case 12: return launch_w3<1, 4, 2, 1, 1>(a, grid, lds, stream);
+        case 13: return launch_w3<1, 4, 3, 1, 1>(a, grid, lds, stream);
+        case 14: return launch_w3<2, 1, 2, 2, 1>(a, grid, lds, stream);
+        case 15: return launch_w3<4, 2, 3, 1, 1>(a, grid, lds, stream);
+        case 16: return launch_w3<4, 1, 2, 1, 2>(a, grid, lds, stream);
+        case 17: return launch_w3<2, 2, 2, 1, 2>(a, grid, lds, stream);
+        case 18: return launch_w3<4, 2, 2, 1, 2>(a, grid, lds, stream);
+        default: return launch_w3<8, 1, 2, 1, 2>(a, grid, lds, stream);
     }
 }
 

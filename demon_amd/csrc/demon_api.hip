@@ -62,9 +62,11 @@ struct Layer {
     // 1-D minimal filtering (conv_wino.hip): k x 1 / 1 x k layers with 3 taps stride 1 or 5 / 7 / 9 taps stride 2; U[e][Cin4][Mpad] in d_w1
     float *d_w1 = nullptr;
     mutable bool w1_dirty = true;
-    // F(4,3) weights of the 3 x 3 stride-1 layers for conv_wino3.hip: U43[ky][e][Cin4][Mpad], 6 planes per kernel row
+    // F(4,3) weights of the 3 x 3 stride-1 layers for conv_wino3.hip: U43[ky][e][Cin4][Mpad], 6 planes per kernel row; for the 3 x 3
+    // stride-2 layers (wino3_stride2) the polyphase F(4,2) + F(4,1) weights, 9 planes per kernel row
     float *d_w3 = nullptr;
     mutable bool w3_dirty = true;
+    bool wino3_stride2() const { return kind == CONV && !scale && Cin >= 16 && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1; }
     // four-outputs-per-window weights of the 3-tap stride-1 / 5-tap stride-2 1-D layers for conv_wino4.hip: U[e][Cin4][Mpad], 6 / 11 planes
     float *d_w4 = nullptr;
     mutable bool w4_dirty = true;
@@ -322,6 +324,12 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
             if (!L->d_w3 || hipMemset(L->d_w3, 0, sizeof(float) * n3) != hipSuccess) return false;
             L->w3_dirty = true;
         }
+    }
+    if (L->wino3_stride2() && L->in.W % 8 == 0 && L->in.W >= 64 && !getenv("DEMON_NO_WINO")) {
+        const size_t n3 = ((size_t)3 * 9 * L->Cin4() + 16) * L->Mpad;
+        L->d_w3 = dev_alloc(c, sizeof(float) * n3);
+        if (!L->d_w3 || hipMemset(L->d_w3, 0, sizeof(float) * n3) != hipSuccess) return false;
+        L->w3_dirty = true;
     }
     if (L->kind == Layer::DENSE && L->in.H * L->in.W == 1 && L->out.H * L->out.W == 1 && !L->scale && dense_stream_geometry_ok(L->Cin, L->Mpad, 1) &&
         (long)L->Cin * L->Mpad >= (1l << 20)) {   // >= 4 MB of weights: below that a dense layer is launch bound whatever streams them
@@ -633,7 +641,7 @@ void refresh_stream_weights(const Layer *L, hipStream_t s)
         L->w1_dirty = false;
     }
     if (L->d_w3 && L->w3_dirty) {   // F(4,3) weights of conv_wino3.hip
-        launch_wino3_repack43(L->d_w3, L->d_wp, L->Cin, L->Cin4(), L->Mpad, s);
+        launch_wino3_repack43(L->d_w3, L->d_wp, L->Cin, L->Cin4(), L->Mpad, L->wino3_stride2() ? 2 : 1, s);
         L->w3_dirty = false;
     }
     if (L->d_w4 && L->w4_dirty) {   // four-outputs-per-window weights of conv_wino4.hip
@@ -768,16 +776,21 @@ bool run_wino1d(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipS
 }
 
 // 3 x 3 stride-1 convs with the transformed input rows stationary (conv_wino3.hip), plan kind 15: variant = workgroup shape.  Uses the
-// transformed weights of the wino1d kernel (d_w1, cross = 3).
-bool wino3_applies(const Layer *L) { return L->d_w1 != nullptr && L->wino1d_kind_of() == 0 && L->wino1d_cross() == 3 && (L->in.W & 1) == 0; }
+// transformed weights of the wino1d kernel (d_w1, cross = 3).  Variants 16 ..: the 3 x 3 stride-2 layers (weights in d_w3).
+bool wino3_applies(const Layer *L)
+{
+    if (L->wino3_stride2()) return L->d_w3 != nullptr;
+    return L->d_w1 != nullptr && L->wino1d_kind_of() == 0 && L->wino1d_cross() == 3 && (L->in.W & 1) == 0;
+}
 
 bool fill_wino3_args(const Layer *L, const ConvArgs &a, int variant, Wino3Args &w)
 {
     if (variant < 0 || variant >= WINO3_VARIANTS) return false;
-    const bool f4 = wino3_variant_f4(variant);
-    if (f4 && !L->d_w3) return false;
-    w.in = a.in; w.out = a.out; w.wu = f4 ? L->d_w3 : L->d_w1; w.bias = a.bias;
-    w.N = a.N; w.Cin = L->Cin; w.Cin4 = L->Cin4(); w.H = a.H; w.W = a.W; w.in_n_stride = a.in_n_stride;
+    const int form = wino3_variant_form(variant);
+    if ((form == 2) != L->wino3_stride2()) return false;
+    if (form >= 1 && !L->d_w3) return false;
+    w.in = a.in; w.out = a.out; w.wu = form >= 1 ? L->d_w3 : L->d_w1; w.bias = a.bias;
+    w.N = a.N; w.Cin = L->Cin; w.Cin4 = L->Cin4(); w.H = a.H; w.W = a.W; w.Ho = a.Ho; w.Wo = a.Wo; w.stride = form == 2 ? 2 : 1; w.in_n_stride = a.in_n_stride;
     w.Cout = L->Cout; w.Mpad = L->Mpad; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
     w.act = a.act; w.xcd = a.xcd;
     return wino3_plan_geometry(w, variant);
@@ -789,7 +802,7 @@ bool run_wino3(const Layer *L, const ConvArgs &a, int variant, hipStream_t s)
     Wino3Args w;
     if (!wino3_applies(L) || !fill_wino3_args(L, a, variant, w)) return false;
     if (!launch_wino3(w, variant, s)) return false;
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino3rows<%s,v%d>", wino3_variant_f4(variant) ? "f4t3x3" : "t3x3", variant);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino3rows<%s,v%d>", wino3_variant_form(variant) == 2 ? "s2t3x3" : (wino3_variant_f4(variant) ? "f4t3x3" : "t3x3"), variant);
     g_last_kernel = g_kernel_tag;
     return true;
 }
@@ -2422,7 +2435,7 @@ int demon_plan_set(demon_ctx *c, int n, const char *layer_name, int kind, int ti
             if (kind == 8 && !wino_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the minimal-filtering kernel applies to transposed convs only");
             if (kind == 10 && !wino1d_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "no 1-D minimal-filtering form for this layer");
             if (kind == 16 && !wino4_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_wino4.hip applies to k x 1 / 1 x k convs with 3 taps stride 1 or 5 taps stride 2 and >= 16 input channels only");
-            if (kind == 15 && !wino3_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_wino3.hip applies to 3 x 3 stride-1 convs with >= 16 input channels and rows of even length only");
+            if (kind == 15 && !wino3_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_wino3.hip applies to 3 x 3 convs with >= 16 input channels, stride 1 (rows of even length) or stride 2 (rows of a multiple of 8 pixels, >= 64)");
             if (kind == 13 && !row_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_row.hip applies to 1 x 7 / 1 x 9 stride-2 convs with at most 32 channels on both sides only");
             if (kind == 12 && !thin_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "conv_thin.hip applies to the 9 x 1 stride-2 first layer (Cin <= 6, Cout <= 32) only");
             if (kind == 11 && !dense_stream_applies(L.get())) return fail(c, DEMON_ERR_INVALID, "the weight-streaming kernel applies to dense layers only");

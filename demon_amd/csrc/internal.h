@@ -299,7 +299,8 @@ struct Wino3Args {
     float *out;
     const float *wu;     // transformed weights U[ky][e][Cin4][Mpad]: F(2,3) 4 planes per kernel row (wino1d_repack_kernel, cross = 3), F(4,3) 6 planes
     const float *bias;
-    int N, Cin, Cin4, H, W;              // stride 1, one zero in front of every row / column: the output has the input's size
+    int N, Cin, Cin4, H, W;              // one zero in front of every row / column; stride 1: the output has the input's size
+    int Ho, Wo, stride;                  // stride 2 (variants 16 ..): Ho = ceil(H / 2), Wo = W / 2, W a multiple of 8
     long in_n_stride;
     int Cout, Mpad;
     long out_n_stride, out_plane;
@@ -308,10 +309,11 @@ struct Wino3Args {
     int xcd;
     unsigned m_colsx, m_rowsy;
 };
-constexpr int WINO3_VARIANTS = 16;   // 8 workgroup shapes (waves along Cout x waves along columns x rows per wave x K groups per step) x {F(2,3), F(4,3)}
+constexpr int WINO3_VARIANTS = 20;   // 8 workgroup shapes (waves along Cout x waves along columns x rows per wave x K groups per step) x {F(2,3), F(4,3)} + 4 for stride 2
 int wino3_variant_bm(int v);
+int wino3_variant_form(int v);  // 0: F(2,3), 1: F(4,3), 2: 3 x 3 stride 2 (polyphase F(4,2) + F(4,1))
 bool wino3_variant_f4(int v);   // F(4,3) tiles of four pixels (own transformed weights: launch_wino3_repack43)
-void launch_wino3_repack43(float *wu, const float *wp, int Cin, int Cin4, int Mpad, hipStream_t s);
+void launch_wino3_repack43(float *wu, const float *wp, int Cin, int Cin4, int Mpad, int stride, hipStream_t s);   // stride 1: 6 planes per kernel row, stride 2: 9
 int wino3_variant_kg(int v);
 int wino3_variant_rows(int v);
 int wino3_variant_cols(int v);

@@ -63,10 +63,14 @@ def kernel_tag(name):
         wide = {(4, 1, 3, 4): 8, (2, 2, 3, 2): 9, (4, 2, 3, 4): 10, (1, 4, 4, 1): 11, (1, 4, 2, 2): 12}   # 48 / 96 tiles per workgroup; one 16-channel block
         v = wide[(wm, wn, tn, kg)] if (wm, wn, tn, kg) in wide else shapes.get((wm, wn, tn), -1) + 4 * (kg - 1)
         return "wino1d<t%d,v%d>" % (3 if kind == 0 else 3 + 2 * kind, v)
-    m = re.search(r"wino3_rows_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (true|false)", name)
-    if m:
+    m = re.search(r"wino3_rows_kernel<(\d+), (\d+), (\d+), (\d+), (true|false), (\d+)", name)
+    if m:   # <WM, WN, TN, KG, MASK, FORM>; FORM 0: F(2,3) tiles, 1: F(4,3) tiles, 2: the stride-2 form
         shape = tuple(map(int, m.groups()[:4]))
-        if m.group(6) == "true":   # F(4,3) tiles
+        form = int(m.group(6))
+        if form == 2:
+            shapes2 = {(4, 1, 2, 1): 16, (2, 2, 2, 1): 17, (4, 2, 2, 1): 18, (8, 1, 2, 1): 19}
+            return "wino3rows<s2t3x3,v%d>" % shapes2.get(shape, -1)
+        if form == 1:
             shapes4 = {(2, 2, 2, 2): 8, (4, 1, 2, 2): 9, (2, 2, 3, 1): 10, (4, 1, 3, 1): 11, (1, 4, 2, 1): 12, (1, 4, 3, 1): 13, (2, 1, 2, 2): 14, (4, 2, 3, 1): 15}
             return "wino3rows<f4t3x3,v%d>" % shapes4.get(shape, -1)
         shapes3 = {(2, 2, 4, 1): 0, (2, 4, 4, 1): 1, (4, 1, 4, 1): 2, (4, 2, 4, 1): 3, (1, 4, 4, 1): 4, (1, 4, 2, 2): 5, (2, 2, 2, 2): 6, (4, 1, 2, 2): 7}

@@ -332,6 +332,50 @@ def test_minimal_filtering_3x3_rows_stationary(gpu_ctx, layer):
         os.environ.pop("DEMON_FORCE_PLAN", None)
 
 
+# (cin, cout, H, W)
+WINO3S2_LAYERS = [(32, 64, 48, 128), (64, 128, 24, 64), (20, 40, 13, 64), (18, 64, 9, 72), (64, 128, 17, 136), (16, 64, 8, 64), (32, 64, 96, 256)]
+
+
+@pytest.mark.parametrize("layer", WINO3S2_LAYERS)
+def test_minimal_filtering_3x3_stride2_rows(gpu_ctx, layer):
+    """conv_wino3.hip, stride-2 form (plan kind 15, variants 16 .. 19; the refinement net's conv1 / conv2, blocks_original.py:484-511):
+    output row r from the transformed input rows 2r - 1, 2r, 2r + 1 kept in LDS, along x the polyphase split with F(4,2) on the even
+    and F(4,1) on the odd samples of a 9-pixel window -- 9 products per 4 outputs and kernel row instead of 12.  1e-5 relative L1
+    against PyTorch for every workgroup shape that fits; odd heights (the zero row below the image), Cin not a multiple of 4, Cout
+    below / across channel blocks, widths that leave tile columns empty; deterministic; the stride-1 variants refuse such a layer."""
+    cin, cout, H, W = layer
+    rng = np.random.default_rng(36)
+    n = 3
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("conv", x, w, b, (2, 2))
+    ran = []
+    try:
+        for v in range(20):
+            os.environ["DEMON_FORCE_PLAN"] = "15,%d,1" % v
+            got = gpu_ctx.conv2d(x, w, b, (2, 2), lrelu=True)
+            tag = gpu_ctx.last_kernel()
+            if v < 16:
+                assert not tag.startswith("wino3rows<"), tag      # stride-1 forms do not take a stride-2 layer
+            if not tag.startswith("wino3rows<"):
+                continue
+            assert tag == "wino3rows<s2t3x3,v%d>" % v, tag
+            ran.append(v)
+            err = rel_l1(got, want)
+            assert err < 1e-5, "variant %d (%s): rel L1 %.3e" % (v, tag, err)
+            np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (2, 2), lrelu=True))
+            lin = gpu_ctx.conv2d(x, w, b, (2, 2), lrelu=False)
+            np.testing.assert_array_equal(np.where(lin >= 0, lin, np.float32(0.1) * lin), got)
+        assert ran, layer
+        if (cin, cout) == (32, 64):
+            assert set(ran) >= {16, 17, 18}, ran
+        if (cin, cout) == (64, 128) and W == 64:
+            assert set(ran) >= {16, 19}, ran
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
 # (cin, cout, kh, kw, sh, sw, H, W)
 WINO4_LAYERS = [(64, 64, 3, 1, 1, 1, 48, 64), (64, 64, 1, 3, 1, 1, 48, 64), (128, 128, 3, 1, 1, 1, 24, 32), (128, 128, 1, 3, 1, 1, 24, 32),
                 (64, 128, 5, 1, 2, 1, 48, 64), (128, 128, 1, 5, 1, 2, 24, 64), (128, 256, 5, 1, 2, 1, 24, 32), (256, 256, 1, 5, 1, 2, 12, 32),

@@ -22,8 +22,9 @@ POINTS_BY_COUNT = {5: [0, 1, -1, 2, -2], 4: [0, 1, -1, 2]}                      
 def toom(m, r):
     """AT (m x a), G (a x r), BT (a x a), a = m + r - 1"""
     a = m + r - 1
-    if r == 1:   # F(2,1): two outputs, one tap: o0 = d0 g, o1 = d1 g
-        return [[Fr(1), Fr(0)], [Fr(0), Fr(1)]], [[Fr(1)], [Fr(1)]], [[Fr(1), Fr(0)], [Fr(0), Fr(1)]]
+    if r == 1:   # F(m,1): m outputs, one tap: o_k = d_k g
+        eye = [[Fr(1) if i == j else Fr(0) for j in range(m)] for i in range(m)]
+        return eye, [[Fr(1)] for _ in range(m)], [row[:] for row in eye]
     pts = [Fr(p) for p in (POINTS[r] if m == 2 else POINTS_BY_COUNT[a - 1])]
     assert len(pts) == a - 1
 
@@ -243,6 +244,7 @@ def render():
     # four outputs per window (conv_wino3.hip, conv_wino4.hip)
     out += render4("Wino43", 3, 1, "3 taps, stride 1, FOUR outputs per window of 6 inputs: 6 products instead of 12 (points 0, +-1, +-2, infinity)")
     out += render4("Wino4K5S2", 5, 2, "5 taps, stride 2, FOUR outputs per window of 11 inputs: polyphase F(4,3) + F(4,2) = 11 products instead of 20")
+    out += render4("Wino4K3S2", 3, 2, "3 taps, stride 2, FOUR outputs per window of 9 inputs: polyphase F(4,2) + F(4,1) = 9 products instead of 12")
     out.append("}  // namespace demon")
     return "\n".join(out) + "\n"
 

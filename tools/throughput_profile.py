@@ -25,6 +25,8 @@ ctx.run_full(n, 3); ctx.synchronize()
 def share(tag):
     if tag.startswith("wino_deconv"):
         return 9 / 16
+    if tag.startswith("wino3rows<s2"):
+        return 9.0 / 12.0
     if tag.startswith("wino3rows<f4") or tag.startswith("wino4<t3"):
         return 0.5
     if tag.startswith("wino4<t5"):
