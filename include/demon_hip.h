@@ -101,7 +101,8 @@ int demon_set_option(demon_ctx *ctx, const char *key, int value);
 int demon_autotune(demon_ctx *ctx, int n);
 /* read back / install launch plans, e.g. to ship the result of one autotune run as a file.  Entry = (kind, tile, ksplit):
  *   kind 0 im2col kernel (conv_mfma.hip), 1 patch-staged kernel (conv_patch.hip; ksplit + 1000 * (pixel-tile shape + 1)),
- *   8 minimal-filtering transposed conv (conv_wino.hip; tile = variant: 32 / 64 / 48 tiles per workgroup),
+ *   8 minimal-filtering transposed conv (conv_wino.hip; tile = variant: 0..3 = 16 output channels x 32 / 64 / 48 / 16 tiles per
+ *      workgroup, 4 / 5 = 32 output channels x 16 / 32 tiles),
  *   10 1-D minimal filtering for k x 1 / 1 x k convs (3 taps stride 1; 5 / 7 / 9 taps stride 2) and 3 x 3 stride-1 convs as three
  *      1 x 3 filters (conv_wino.hip; tile = workgroup shape 0..10); 9 is not used (a removed experiment),
  *   11 weight-streaming kernel for the dense layers (dense_stream.hip: dense5 of v2, motion_fc1; tile 0 / 1 = default /
@@ -111,10 +112,11 @@ int demon_autotune(demon_ctx *ctx, int n);
  *        3 small-Cout VALU kernel, 4 register-streaming kernel (conv_stream.hip), 5 fragment-tiled kernel (conv_frag.hip),
  *        6 / 7 on the k x 1 layer of a stride-1 pair: the pair runs as ONE chained launch of conv_frag / conv_stream variant `tile`;
  *        14 marker on the k x 1 layer of a conv_pair.hip pair: the fused launch measured faster at this batch size;
- *        15 3 x 3 stride-1 conv as three 1 x 3 minimal-filtering row filters with the transformed input rows stationary
- *           (conv_wino3.hip; tile = workgroup shape 0..7 on F(2,3) tiles, 8..15 on F(4,3) tiles),
+ *        15 3 x 3 conv as three 1 x 3 minimal-filtering row filters with the transformed input rows stationary (conv_wino3.hip;
+ *           stride 1: tile = workgroup shape 0..7 on F(2,3) tiles, 8..15 on F(4,3) tiles; stride 2 (rows of a multiple of 8 pixels):
+ *           tile 16..19, polyphase F(4,2) + F(4,1)),
  *        16 k x 1 / 1 x k conv with four outputs per window (conv_wino4.hip: F(4,3) for 3 taps stride 1, F(4,3) + F(4,2) for 5 taps
- *           stride 2; tile = workgroup shape 0..7);
+ *           stride 2; tile = workgroup shape 0..8);
  *   tile = tile / variant id of that kernel; ksplit = K slices across workgroups, combined by a conv_splitk_reduce launch.
  *   demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
 int demon_num_layers(const demon_ctx *ctx);
