@@ -143,3 +143,35 @@ def test_kernel_names_round_trip():
         shown = rocprof_kernel_name(tag + "+splitk")
         assert shown.split("<")[0] == "demon::" + tag.split("<")[0] + "_kernel"
         assert shown.split("<")[0].replace("demon::", "") in name
+    # the minimal-filtering kernels whose tag family is not the kernel's name
+    more = {
+        "void demon::wino3_rows_kernel<2, 2, 4, 1, false, 0>(demon::Wino3Args)": "wino3rows<t3x3,v0>",
+        "void demon::wino3_rows_kernel<4, 1, 3, 1, false, 1>(demon::Wino3Args)": "wino3rows<f4t3x3,v11>",
+        "void demon::wino3_rows_kernel<8, 1, 2, 1, false, 2>(demon::Wino3Args)": "wino3rows<s2t3x3,v19>",
+        "void demon::wino4_kernel<1, 0, 4, 2, 2, 2, false, false>(demon::Wino4Args)": "wino4<t5,v4>",
+        "void demon::wino4_kernel<0, 1, 2, 2, 2, 1, false, false>(demon::Wino4Args)": "wino4<t3,v8>",
+    }
+    for name, tag in more.items():
+        assert kernel_tag(name) == tag
+
+
+def test_pmc_family_covers_every_contraction_kernel():
+    """tools/pmc_summary.py averages the HBM counters over the launches bench.py's `roofline_family` counts; its list of kernel names must
+    know every family that bench.py names there (round 4 shipped a summary that had left the wino3_rows / wino4 launches out)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_summary", os.path.join(ROOT, "tools", "pmc_summary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    m = re.search(r'"kernel": "all conv / deconv / dense launches \(([^)]*) kernels\)"', src)
+    assert m, "bench.py no longer names the families of roofline_family"
+    families = [f.strip() for f in m.group(1).split(",")]
+    assert len(families) >= 16
+    symbol = {"wino3rows": "wino3_rows_kernel", "deconv4": "deconv4_kernel"}
+    for fam in families:
+        assert symbol.get(fam, fam + "_kernel") in mod.CONTRACTION_KERNELS, fam
+    # and every kernel source that launches a contraction kernel is behind one of the names
+    for k in mod.CONTRACTION_KERNELS:
+        assert any(k + "<" in open(os.path.join(ROOT, "demon_amd", "csrc", f)).read() or k + "(" in open(os.path.join(ROOT, "demon_amd", "csrc", f)).read()
+                   for f in os.listdir(os.path.join(ROOT, "demon_amd", "csrc")) if f.endswith(".hip")), k
+
