@@ -47,6 +47,8 @@ def golden(request):
         manifest = json.load(f)
     assert manifest["format_version"] == G.FORMAT_VERSION
     assert (manifest["backend"] == "oracle-selftest") == (request.param == "selftest")   # a self-test dump must never sit in tests/golden/tf
+    # ... and neither must a dry run of the tool on the TensorFlow emulator (oracle/tf1, tests/test_tf1_emulator.py)
+    assert not str(manifest["versions"].get("tensorflow", "")).endswith("-emulated")
     return d, manifest
 
 

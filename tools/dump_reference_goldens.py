@@ -114,7 +114,8 @@ class TFBackend(object):
         import ast
         from PIL import Image
         path = os.path.join(self.reference, "examples", "example.py")
-        tree = ast.parse(open(path).read())
+        with open(path) as f:
+            tree = ast.parse(f.read())
         fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "prepare_input_data"][0]
         ns = {"np": np}
         try:

@@ -229,10 +229,13 @@ def layer_cases(seed=11):
         cases.append({"kind": "convrelu2_same", "tag": "convrelu2_same/k%d_s%d_%dto%d_%d_%dx%d" % (k, stride, cin, cy, cx, h, w), "x": x(2, cin, h, w),
                       "params": {"num_outputs": [cy, cx], "kernel_size": k, "stride": stride}})
     cases.append({"kind": "upsample_prediction", "tag": "upsample_prediction/4to2_6x8", "x": x(2, 4, 6, 8), "params": {"num_outputs": 2}})
+    # features_direct must have num_outputs channels: blocks_original.py:109-110 crops the upconv with tf.slice(tmp, [0,0,1,1],
+    # features_direct.get_shape()) -- ALL four dimensions of features_direct, so fewer channels there would also cut the upconv's
+    # channels (found by the dry run of the dump tool on oracle/tf1; every refine* of the nets has equal channel counts)
     cases.append({"kind": "refine", "tag": "refine/32to16_6x8", "x": x(2, 32, 6, 8),
-                  "params": {"num_outputs": 16}, "features_direct": x(2, 8, 12, 16), "upsampled_prediction": x(2, 2, 12, 16)})
+                  "params": {"num_outputs": 16}, "features_direct": x(2, 16, 12, 16), "upsampled_prediction": x(2, 2, 12, 16)})
     cases.append({"kind": "refine", "tag": "refine/16to8_5x7_nopred", "x": x(1, 16, 5, 7),
-                  "params": {"num_outputs": 8}, "features_direct": x(1, 4, 10, 14), "upsampled_prediction": None})
+                  "params": {"num_outputs": 8}, "features_direct": x(1, 8, 10, 14), "upsampled_prediction": None})
     cases.append({"kind": "flatten_dense", "tag": "flatten_dense/8x3x4to16", "x": x(3, 8, 3, 4), "params": {"units": 16, "activation": True}})
     return cases
 
