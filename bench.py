@@ -264,6 +264,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
+        timed.local_s = dt                  # this rank's own clock (per_rank below); the reported time is the MAX over the ranks
         if distributed:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,6 +272,7 @@ def main():
         return dt
 
     elapsed = timed(lambda k: group.run_resident(n, k, args.iterations, boot_only), group.synchronize)
+    local_elapsed = timed.local_s
     out = ctx.download_outputs(n, with_depth0=not boot_only)
     finite = all(np.isfinite(v).all() for v in out.values())
     for c in group.ctxs[1:]:
@@ -280,8 +282,19 @@ def main():
     if args.lanes > 1 and shipped_plans:
         ctx.load_tuned_plan(n)   # ... and the plan tuned for one pass at a time, when the lanes ran a throughput-mode plan
     # the same K steps one at a time on one lane (round 1-3's protocol), for comparison
-    elapsed_single = elapsed if args.lanes == 1 else timed(
+    # (re-measured even when the calibration kept ONE lane, unless that lane already ran the latency plan with its side branches on)
+    single_is_headline = args.lanes == 1 and not (shipped_plans and plan_lanes > 1) and ctx.get_option("side_branches") == 1
+    elapsed_single = elapsed if single_is_headline else timed(
         lambda k: [ctx.run_bootstrap(n) if boot_only else ctx.run_full(n, args.iterations) for _ in range(k)], ctx.synchronize)
+    local_single = timed.local_s
+    # every rank's own numbers (its clock, its calibration): the first multi-GPU run must be diagnosable from the one JSON line
+    mine = {"rank": rank, "pairs_per_s": args.batch * args.steps / local_elapsed, "single_lane_pairs_per_s": args.batch * args.steps / local_single,
+            "lanes": args.lanes, "lanes_mapping": lane_mapping,
+            "lanes_calibration_pairs_per_s": {str(k): round(v, 1) for k, v in lane_rates.items()} if lane_rates else None}
+    per_rank = [mine]
+    if distributed:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     out1 = ctx.download_outputs(n, with_depth0=not boot_only)
     if args.lanes > 1 and shipped_plans:
         ctx.load_tuned_plan(n, lanes=plan_lanes)   # the per-launch profile below is of the kernels the headline ran
@@ -310,6 +323,11 @@ def main():
                        "rccl_nranks": rccl_nranks,
                        "launch_plan": plan_src, "plan_setup_s": round(t_tune, 2)},
             "outputs_finite": bool(finite),
+            # one batch at a time on one lane (rounds 1-3's protocol, BASELINE configs[2] read strictly): the like-for-like trend number
+            "value_single_lane": pairs / elapsed_single,
+            "per_rank": {"pairs_per_s_min": min(r["pairs_per_s"] for r in per_rank), "pairs_per_s_max": max(r["pairs_per_s"] for r in per_rank),
+                         "single_lane_pairs_per_s_min": min(r["single_lane_pairs_per_s"] for r in per_rank),
+                         "lanes": [r["lanes"] for r in per_rank], "ranks": per_rank},
             "single_lane": {"pairs_per_s": pairs / elapsed_single, "ms_per_step": 1e3 * elapsed_single / args.steps,
                             "lane0_outputs_rel_l1": lanes_vs_single, "lane0_outputs_match": bool(lanes_vs_single <= 1e-4),
                             "note": "the same K steps one at a time on one lane (side branches of the pass on a second stream, as in rounds 1-3)"},

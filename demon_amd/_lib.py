@@ -20,6 +20,16 @@ class DemonOutputs(ctypes.Structure):
         "predict_normal2", "predict_rotation", "predict_translation", "predict_scale")]
 
 
+class LanesEntry(ctypes.Structure):
+    _fields_ = [("lanes", ctypes.c_int), ("placeholder_streams", ctypes.c_int), ("pairs_per_s", ctypes.c_float)]
+
+
+class LanesResult(ctypes.Structure):
+    """demon_lanes_result (DEMON_LANES_TABLE_CAP = 64)"""
+    _fields_ = [("lanes", ctypes.c_int), ("placeholder_streams", ctypes.c_int), ("pairs_per_s", ctypes.c_float), ("ntable", ctypes.c_int),
+                ("table", LanesEntry * 64)]
+
+
 class LaunchRecord(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 64), ("kernel", ctypes.c_char * 32), ("flops", ctypes.c_double),
                 ("bytes", ctypes.c_double), ("ms", ctypes.c_float), ("reduce_ms", ctypes.c_float)]
@@ -54,6 +64,10 @@ SIGNATURES = {
     "demon_set_weights_blob": (_I, [_P, c_float_p, ctypes.c_int64]),
     "demon_set_weights_blob_device": (_I, [_P, _P, ctypes.c_int64]),
     "demon_set_option": (_I, [_P, ctypes.c_char_p, _I]),
+    "demon_get_option": (_I, [_P, ctypes.c_char_p, c_int_p]),
+    "demon_plan_clear": (_I, [_P, _I]),
+    "demon_lanes_apply": (_I, [ctypes.POINTER(_P), _I, _I]),
+    "demon_lanes_calibrate": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I, _I, _I, ctypes.POINTER(LanesResult)]),
     "demon_autotune": (_I, [_P, _I]),
     "demon_num_layers": (_I, [_P]),
     "demon_plan_get": (_I, [_P, _I, _I, ctypes.c_char_p, _I, c_int_p, c_int_p, c_int_p]),

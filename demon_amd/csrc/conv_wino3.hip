@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
             const bool ok = uv & ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W);
             goff[i][e] = ok ? 4 * (k * HW + gy * a.W + gx) : OOB;
         }
-        tw[0][i] = uv ? 2 * ASZ + k * TP + slot : 2 * ASZ + 2 * TSZ + tid * 4;   // (units past the end write their four values to the thread's dummy slot)
+        tw[0][i] = uv ? 2 * ASZ + k * TP + slot : 2 * ASZ + 2 * TSZ + tid * 4;   // (units past the end write all their values to the first word of the thread's dummy slot)
         tw[1][i] = uv ? tw[0][i] + TSZ : tw[0][i];
         asm volatile("" : "+v"(tw[1][i]));
         lastmask |= ((last_c0 + k < a.Cin) ? 1u : 0u) << i;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
 #pragma unroll
                 for (int e = 0; e < NUV; ++e) T[e * CKS * TP] = t[e];
             } else {
-                const int st = (tid + i * NT < NUNIT) ? CKS * TP : 1;
+                const int st = (tid + i * NT < NUNIT) ? CKS * TP : 0;   // (units past the end: every value to the one dummy word)
 #pragma unroll
                 for (int e = 0; e < NUV; ++e) T[e * st] = t[e];
             }

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <functional>
 #include <mutex>
 #include <map>
@@ -173,6 +174,7 @@ struct demon_ctx {
     std::vector<hipStream_t> tune_streams;   // throughput-mode autotune (option tune_lanes): concurrent replays need streams of their own
     std::vector<hipEvent_t> tune_events;
     int opt_tune_lanes = 1;
+    std::vector<hipStream_t> placeholder_streams;   // demon_lanes_apply / demon_lanes_calibrate: idle streams that shift the lanes' stream -> hardware-queue mapping (owned by lane 0)
     std::vector<hipEvent_t> events;  // fork / join events, one per use inside a sequence
     int opt_side_branches = 1;
     int opt_fused_pairs = 1;  // conv_pair.hip for the pairs conv_pair_applies() selects
@@ -1766,7 +1768,11 @@ void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t 
         if ((st.fused == 1 && !c->opt_fused_inputs) || (st.fused == 2 && c->opt_fused_inputs)) continue;
         // diagnostic hook (tools/ablate_lanes.py): DEMON_SKIP_STEPS="sub1,sub2" leaves out the steps whose name contains one of the
         // substrings -- WRONG results, used only to read off what a group of layers costs while several passes are in flight
-        static const std::string skip = getenv("DEMON_SKIP_STEPS") ? getenv("DEMON_SKIP_STEPS") : "";
+        static const std::string skip = [] {
+            const char *e = getenv("DEMON_SKIP_STEPS");
+            if (e && *e) fprintf(stderr, "libdemon_hip: DEMON_SKIP_STEPS=%s is set -- steps are LEFT OUT of every pass, all results are WRONG (diagnostic for tools/ablate_lanes.py only)\n", e);
+            return std::string(e ? e : "");
+        }();
         if (!skip.empty()) {
             bool drop = false;
             for (size_t b = 0; b < skip.size() && !drop;) {
@@ -2033,6 +2039,7 @@ int demon_destroy(demon_ctx *c)
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     for (hipStream_t st : c->tune_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+    for (hipStream_t st : c->placeholder_streams) hipStreamDestroy(st);
     for (hipEvent_t e : c->tune_events) hipEventDestroy(e);
     for (hipEvent_t e : c->events) if (e) hipEventDestroy(e);
     for (void *p : c->allocations) hipFree(p);
@@ -2322,6 +2329,20 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
     return fail(c, DEMON_ERR_NOT_FOUND, std::string("unknown option ") + key);
 }
 
+int demon_get_option(const demon_ctx *c, const char *key, int *value)
+{
+    if (!c || !key || !value) return DEMON_ERR_INVALID;
+    if (!strcmp(key, "hipgraph")) *value = c->opt_hipgraph;
+    else if (!strcmp(key, "flow_to_depth_method")) *value = c->opt_f2d_method;
+    else if (!strcmp(key, "reuse_image_features")) *value = c->opt_reuse_image;
+    else if (!strcmp(key, "fused_pairs")) *value = c->opt_fused_pairs;
+    else if (!strcmp(key, "fused_inputs")) *value = c->opt_fused_inputs;
+    else if (!strcmp(key, "tune_lanes")) *value = c->opt_tune_lanes;
+    else if (!strcmp(key, "side_branches")) *value = c->opt_side_branches;
+    else return DEMON_ERR_NOT_FOUND;
+    return DEMON_OK;
+}
+
 // A chainable pair: the two separately tuned launches against every chained variant that fits; the k x 1 layer's plan becomes
 // kind 6 / 7 when a chain is faster.
 int autotune_chain(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
@@ -2373,6 +2394,7 @@ int autotune_fused_pair(demon_ctx *c, Layer *Ly, Layer *Lx, int n)
 int demon_autotune(demon_ctx *c, int n)
 {
     if (!c || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "batch size out of range [1, max_batch]");
+    if (!c->stream) return fail(c, DEMON_ERR_NOT_READY, kNoStream);   // (the repack kernels and every timed replay run on the context's stream)
     hipSetDevice(c->device);
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);  // captured launches embed the old choices
     c->graphs.clear();
@@ -2409,6 +2431,15 @@ int demon_plan_get(const demon_ctx *c, int n, int layer_index, char *name, int n
     if (kind) *kind = it->second.kind;
     if (tile) *tile = it->second.tile;
     if (ksplit) *ksplit = it->second.ksplit;
+    return DEMON_OK;
+}
+
+int demon_plan_clear(demon_ctx *c, int n)
+{
+    if (!c || n < 1 || n > c->max_batch) return fail(c, DEMON_ERR_INVALID, "batch size out of range [1, max_batch]");
+    for (auto &g : c->graphs) hipGraphExecDestroy(g.second);   // captured launches embed the old choices
+    c->graphs.clear();
+    for (auto &L : c->layers) L->tuned.erase(n);
     return DEMON_OK;
 }
 
@@ -2532,6 +2563,9 @@ int demon_release_streams(demon_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipStreamDestroy(c->stream)); c->stream = nullptr; }
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
+    // the throughput-mode tuner's streams take part in the stream -> hardware-queue mapping as well (re-created on demand)
+    for (hipStream_t st : c->tune_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+    c->tune_streams.clear();
     return DEMON_OK;
 }
 
@@ -2544,6 +2578,104 @@ int demon_acquire_streams(demon_ctx *c)
         c->side_stream = nullptr;
         c->opt_side_branches = 0;
     }
+    return DEMON_OK;
+}
+
+// ---- lanes: several contexts on one GPU, their streams mapped onto hardware queues by measurement (demon_amd/lanes.py is the
+// Python face of these two; INTEGRATION.md section 6 shows them from C)
+namespace {
+int lanes_check(demon_ctx *const *ctxs, int nctx)
+{
+    if (!ctxs || nctx < 1 || nctx > DEMON_LANES_MAX || !ctxs[0]) return DEMON_ERR_INVALID;
+    for (int i = 0; i < nctx; ++i) {
+        if (!ctxs[i]) return fail(ctxs[0], DEMON_ERR_INVALID, "null context in the lane array");
+        if (ctxs[i]->device != ctxs[0]->device) return fail(ctxs[0], DEMON_ERR_INVALID, "the lanes of a group live on one device");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(ctxs[0], DEMON_ERR_INVALID, "the same context twice in the lane array");
+    }
+    return DEMON_OK;
+}
+}  // namespace
+
+int demon_lanes_apply(demon_ctx *const *ctxs, int nctx, int placeholder_streams)
+{
+    int r = lanes_check(ctxs, nctx);
+    if (r) return r;
+    demon_ctx *c0 = ctxs[0];
+    if (placeholder_streams < 0 || placeholder_streams > DEMON_LANES_MAX_PLACEHOLDERS) return fail(c0, DEMON_ERR_INVALID, "placeholder_streams out of range");
+    hipSetDevice(c0->device);
+    for (int i = 0; i < nctx; ++i)
+        if ((r = demon_release_streams(ctxs[i]))) return r == DEMON_ERR_HIP ? fail(c0, r, "lane " + std::to_string(i) + ": " + ctxs[i]->err) : r;
+    for (hipStream_t st : c0->placeholder_streams) hipStreamDestroy(st);
+    c0->placeholder_streams.clear();
+    for (int i = 0; i < placeholder_streams; ++i) {
+        hipStream_t st = nullptr;
+        HIP_TRY(c0, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        c0->placeholder_streams.push_back(st);
+    }
+    for (int i = 0; i < nctx; ++i)
+        if ((r = demon_acquire_streams(ctxs[i]))) return r == DEMON_ERR_HIP ? fail(c0, r, "lane " + std::to_string(i) + ": " + ctxs[i]->err) : r;
+    return DEMON_OK;
+}
+
+int demon_lanes_calibrate(demon_ctx *const *ctxs, int nctx, int n, int iterations, int bootstrap_only, int steps_per_lane,
+                          int max_placeholders, demon_lanes_result *res)
+{
+    int r = lanes_check(ctxs, nctx);
+    if (r) return r;
+    demon_ctx *c0 = ctxs[0];
+    if (!res || steps_per_lane < 1 || max_placeholders < 0 || max_placeholders > DEMON_LANES_MAX_PLACEHOLDERS) return fail(c0, DEMON_ERR_INVALID, "bad argument");
+    if (iterations < 0 || iterations > 64) return fail(c0, DEMON_ERR_INVALID, "iterations out of range");
+    for (int i = 0; i < nctx; ++i)
+        if ((r = check_batch(ctxs[i], n))) return i ? fail(c0, r, "lane " + std::to_string(i) + ": " + ctxs[i]->err) : r;
+    hipSetDevice(c0->device);
+    memset(res, 0, sizeof *res);
+    auto sync = [&](int k) -> int {
+        for (int i = 0; i < k; ++i) HIP_TRY(c0, hipStreamSynchronize(ctxs[i]->stream));
+        return DEMON_OK;
+    };
+    auto rate = [&](int k, float *out) -> int {
+        double best = 0.0;
+        for (int round = 0; round < 2; ++round) {   // (the first round also instantiates graphs / warms caches)
+            int rr = sync(nctx);
+            if (rr) return rr;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < steps_per_lane * k; ++i) {
+                demon_ctx *c = ctxs[i % k];
+                if ((rr = run_sequence(c, bootstrap_only ? SEQ_BOOT : SEQ_FULL, n, bootstrap_only ? 0 : iterations)))
+                    return rr == DEMON_ERR_HIP && c != c0 ? fail(c0, rr, c->err) : rr;
+            }
+            if ((rr = sync(k))) return rr;
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            best = std::max(best, (double)n * steps_per_lane * k / s);
+        }
+        *out = (float)best;
+        return DEMON_OK;
+    };
+    int current = (int)c0->placeholder_streams.size();
+    if (nctx == 1) max_placeholders = 0;     // one lane does not care where its stream lands
+    res->lanes = 1;
+    res->placeholder_streams = 0;
+    res->pairs_per_s = -1.0f;
+    for (int pad = 0; pad <= max_placeholders; ++pad) {
+        if (pad != current || pad == 0) {   // (pad 0 is applied too: the measurement must not depend on a previous call's placeholders)
+            if ((r = demon_lanes_apply(ctxs, nctx, pad))) return r;
+            current = pad;
+        }
+        for (int k = 1; k <= nctx; ++k) {
+            if (pad && k == 1) continue;
+            float v = 0.0f;
+            if ((r = rate(k, &v))) return r;
+            if (res->ntable < DEMON_LANES_TABLE_CAP) {
+                res->table[res->ntable].lanes = k;
+                res->table[res->ntable].placeholder_streams = pad;
+                res->table[res->ntable].pairs_per_s = v;
+                ++res->ntable;
+            }
+            if (v > res->pairs_per_s) { res->pairs_per_s = v; res->lanes = k; res->placeholder_streams = pad; }
+        }
+    }
+    if (res->placeholder_streams != current && (r = demon_lanes_apply(ctxs, nctx, res->placeholder_streams))) return r;
     return DEMON_OK;
 }
 
@@ -2898,6 +3030,7 @@ int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int
                       int tile, int ksplit, int iters, float *avg_ms, double *flops)
 {
     if (!c || !avg_ms || iters < 1 || n < 1 || kind < 0 || kind > 2 || (tile >= TILE_COUNT && tile < 100) || (tile >= 100 + PTILE_COUNT && tile < 200) || (tile >= 200 + STREAM_VARIANTS && tile < 300) || (tile >= 300 + FRAG_VARIANTS && tile < 400) || (tile >= 400 + WINO1D_VARIANTS && tile != 500)) return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (!c->stream) return fail(c, DEMON_ERR_NOT_READY, kNoStream);
     hipSetDevice(c->device);
     demon_ctx scratch;
     scratch.device = c->device;

@@ -148,20 +148,35 @@ class DemonContext:
             m = re.match(re.escape(stem) + r"(\d+)\.json$", os.path.basename(path))
             if m:
                 have[int(m.group(1))] = path
-        if lanes > 1:   # throughput-mode plans replace the latency plan of the same batch size
+        if lanes > 1:   # throughput-mode plans replace the latency plan of the same batch size: per batch size the plan tuned for
+            tuned = {}  # exactly `lanes` passes in flight, else the one tuned for the nearest lane count
             for path in sorted(glob.glob(os.path.join(directory, stem + "*_l*.json"))):
                 m = re.match(re.escape(stem) + r"(\d+)_l(\d+)\.json$", os.path.basename(path))
                 if m:
-                    have[int(m.group(1))] = path
+                    tuned.setdefault(int(m.group(1)), {})[int(m.group(2))] = path
+            for b, by_l in tuned.items():
+                have[b] = by_l[min(by_l, key=lambda l: (abs(l - int(lanes)), l))]
         if not have or (int(n) not in have and not nearest):
             return 0
         src = int(n) if int(n) in have else min(have, key=lambda b: abs(np.log(b / float(n))))
         with open(have[src]) as f:
-            self.set_plan(n, json.load(f)["plan"])
+            plan = json.load(f)["plan"]
+        self.clear_plan(n)      # a layer only the previous plan mentioned (e.g. a kind-14 marker) must not survive the swap
+        self.set_plan(n, plan)
+        self.plan_file = os.path.basename(have[src])
         return src
 
     def set_option(self, key, value):
         self._check(self.lib.demon_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = ctypes.c_int()
+        self._check(self.lib.demon_get_option(self.h, key.encode(), ctypes.byref(v)))
+        return int(v.value)
+
+    def clear_plan(self, n):
+        """demon_plan_clear: forgets every plan entry of batch size n (before another plan for the same n is installed)"""
+        self._check(self.lib.demon_plan_clear(self.h, int(n)))
 
     # ---- networks (NCHW numpy in, dict of NCHW numpy out) -------------------------------------------------
     def _alloc_outputs(self, n):

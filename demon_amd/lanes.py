@@ -15,7 +15,11 @@ same two lanes).  One stream per lane is deterministic.
 How many lanes pay off depends on how the HIP runtime maps the lanes' streams onto hardware queues, which in turn depends on
 every other stream alive in the process (another context, torch's streams): the same three lanes measured 3660-4176 pairs/s in
 two different processes.  `calibrate()` therefore MEASURES the lane counts 1 .. len(group) on the spot (a few steps each, on the
-lanes' resident inputs) and keeps the best prefix of the lanes; it is set-up work like the launch-plan tuning.
+lanes' resident inputs) and keeps the best prefix of the lanes; it is set-up work like the launch-plan tuning.  The measurement
+itself lives behind the C ABI (`demon_lanes_calibrate` / `demon_lanes_apply`, include/demon_hip.h; round 5) so that a C / C++
+host gets the same behaviour; this class is its Python face.  A winner is remembered per process environment (`mapping_key()`:
+device, shape, batch, lane count, WORLD_SIZE, torch loaded or not) in the in-process cache and, when $DEMON_LANES_CACHE names a
+JSON file, across processes: `calibrate(reuse=True)` then re-applies it with `demon_lanes_apply` instead of measuring again.
 
 Weights exist once per lane (device-to-device copy of the packed slab: demon_copy_weights_from); nothing is shared at run time,
 so lanes need no locking: a lane is used by one host thread at a time.
@@ -24,6 +28,8 @@ from .engine import DemonContext
 
 
 class LaneGroup:
+    _cache = {}     # mapping_key -> {"lanes", "placeholder_streams", "pairs_per_s"}
+
     def __init__(self, weights=None, lanes=3, batch=32, height=192, width=256, device=0, version=1, first=None, plan_batch=None):
         """first: an existing context that becomes lane 0 (it already holds its weights, e.g. a rank's context after the RCCL
         broadcast); otherwise lane 0 is created here and takes `weights` (dict tf name -> array)."""
@@ -31,24 +37,26 @@ class LaneGroup:
             raise ValueError("lanes must be >= 1")
         self.batch, self.H, self.W, self.device, self.version = batch, height, width, device, version
         self._owns_first = first is None
+        self._plan_batch = plan_batch or batch
         if first is None:
             first = DemonContext(device, batch, height, width, version)
             first.set_weights(weights)
-            first.load_tuned_plan(plan_batch or batch, lanes=lanes)
+            first.load_tuned_plan(self._plan_batch, lanes=lanes)
+        self._first_side = first.get_option("side_branches")     # a borrowed lane 0 goes back the way it came
         self.ctxs = [first]
-        plan = first.get_plan(plan_batch or batch)
+        plan = first.get_plan(self._plan_batch)
         for _ in range(lanes - 1):
             c = DemonContext(device, batch, height, width, version)
             c.copy_weights_from(first)          # the packed slab, device to device
             if plan:
-                c.set_plan(plan_batch or batch, plan)
+                c.set_plan(self._plan_batch, plan)
             self.ctxs.append(c)
+        self._requested = lanes
         self._side_off = lanes > 1
         if self._side_off:
             for c in self.ctxs:
                 c.set_option("side_branches", 0)
         self._next = 0
-        self._pads = []
         self.mapping = None
 
     def __len__(self):
@@ -58,67 +66,113 @@ class LaneGroup:
         for i, c in enumerate(self.ctxs):
             if i or self._owns_first:
                 c.close()
-            elif self._side_off:
-                c.set_option("side_branches", 1)   # a borrowed lane 0 goes back the way it came
+            else:
+                self._apply(0, ctxs=[c])           # its placeholder streams go; the borrowed context keeps working
+                c.set_option("side_branches", self._first_side)
         self.ctxs = []
-        for p in self._pads:
-            p.close()
-        self._pads = []
 
-    def _remap(self, pad):
-        """every lane gives its HIP streams back, `pad` placeholder streams are created (one-stream contexts that stay alive with the
-        group), and the lanes take new streams in order: another stream -> hardware-queue mapping for the same lanes"""
-        for c in self.ctxs:
-            c.synchronize()
-            c.release_streams()
-        for p in self._pads:
-            p.close()
-        self._pads = [DemonContext.ops_only(self.device) for _ in range(pad)]
-        for c in self.ctxs:
-            c.acquire_streams()
+    # ---- the C ABI underneath ------------------------------------------------------------------------------------------------------
+    def _handles(self, ctxs=None):
+        import ctypes
+        ctxs = self.ctxs if ctxs is None else ctxs
+        return (ctypes.c_void_p * len(ctxs))(*[c.h for c in ctxs]), len(ctxs)
 
-    def _rate(self, k, n, iterations, bootstrap_only, steps_per_lane):
-        import time
-        best = 0.0
-        for _ in range(2):   # (the first round also instantiates graphs / warms caches)
-            self.synchronize()
-            t0 = time.perf_counter()
-            for i in range(steps_per_lane * k):
-                c = self.ctxs[i % k]
-                c.run_bootstrap(n) if bootstrap_only else c.run_full(n, iterations)
-            for c in self.ctxs[:k]:
-                c.synchronize()
-            best = max(best, n * steps_per_lane * k / (time.perf_counter() - t0))
-        return best
+    def _apply(self, placeholder_streams, ctxs=None):
+        """demon_lanes_apply: every lane gives its HIP streams back, `placeholder_streams` idle streams are created (owned by lane 0)
+        and the lanes take new streams in order: another stream -> hardware-queue mapping for the same lanes"""
+        arr, k = self._handles(ctxs)
+        first = (self.ctxs if ctxs is None else ctxs)[0]
+        first._check(first.lib.demon_lanes_apply(arr, k, int(placeholder_streams)))
 
-    def calibrate(self, n, iterations=3, bootstrap_only=False, steps_per_lane=4, candidates=None, pads=(0, 1, 2, 3)):
-        """Measures (inputs must be resident in every lane) the rate of `steps_per_lane * k` steps on the first k lanes for every
-        candidate k, under the stream mapping the lanes were created with and -- pads -- after re-creating the lanes' streams behind
-        1 .. 3 placeholder streams (the mapping of HIP streams onto hardware queues depends on every stream alive in the process:
-        the same lanes measured 3480 .. 4220 pairs/s over 0 .. 3 placeholders, `gpurun_out/r5m/pad.txt`).  Keeps the best
-        (placeholders, k), closes the lanes beyond k and returns {"k@placeholders": pairs/s}.  Lane 0 alone (k = 1) runs without
-        side branches here, so the comparison is between stream mappings only."""
-        ks = [k for k in sorted(set(candidates or range(1, len(self.ctxs) + 1))) if 1 <= k <= len(self.ctxs)]
-        rates, best, current = {}, (-1.0, ks[0], 0), 0
-        for pad in ([0] + [p for p in pads if p]) if len(self.ctxs) > 1 else [0]:
-            if pad != current:
-                self._remap(pad)
-                current = pad
-            for k in ks:
-                if pad and k == 1:
-                    continue          # one lane does not care where its stream lands
-                r = self._rate(k, n, iterations, bootstrap_only, steps_per_lane)
-                rates["%d@%d" % (k, pad)] = r
-                if r > best[0]:
-                    best = (r, k, pad)
-        if best[2] != current:
-            self._remap(best[2])
-        keep = best[1]
+    def mapping_key(self):
+        """what a measured (lanes, placeholder streams) winner depends on, as far as this process can tell: the streams other
+        libraries hold (torch.distributed / RCCL under a launcher, torch itself) shift the mapping"""
+        import os
+        import sys
+        return "dev%d_%dx%d_v%d_n%d_l%d_ws%s_torch%d" % (self.device, self.H, self.W, self.version, self.batch, self._requested,
+                                                         os.environ.get("WORLD_SIZE", "1"), int("torch" in sys.modules))
+
+    @classmethod
+    def _cache_file(cls):
+        import os
+        return os.environ.get("DEMON_LANES_CACHE") or None
+
+    @classmethod
+    def _cache_load(cls):
+        import json
+        import os
+        path = cls._cache_file()
+        if path and os.path.isfile(path):
+            try:
+                with open(path) as f:
+                    for k, v in json.load(f).items():
+                        cls._cache.setdefault(k, v)
+            except (OSError, ValueError):
+                pass
+
+    @classmethod
+    def _cache_store(cls):
+        import json
+        path = cls._cache_file()
+        if path:
+            try:
+                with open(path, "w") as f:
+                    json.dump(cls._cache, f, indent=1, sort_keys=True)
+            except OSError:
+                pass
+
+    def _keep(self, keep, placeholder_streams, rate):
         for c in self.ctxs[keep:]:
             c.close()
         del self.ctxs[keep:]
         self._next = 0
-        self.mapping = {"lanes": keep, "placeholder_streams": best[2], "pairs_per_s": best[0]}
+        if keep == 1 and self._side_off:
+            # one lane left: it is a plain context again -- side branches back on and the latency plan of its batch size instead of
+            # the throughput-mode one (a lone lane on the group's settings is slower than a context that never was in a group)
+            self.ctxs[0].set_option("side_branches", self._first_side if not self._owns_first else 1)
+            if self._owns_first:
+                self.ctxs[0].load_tuned_plan(self._plan_batch, lanes=1)
+            self._side_off = False
+        self.mapping = {"lanes": keep, "placeholder_streams": placeholder_streams, "pairs_per_s": rate}
+
+    def calibrate(self, n, iterations=3, bootstrap_only=False, steps_per_lane=4, candidates=None, pads=(0, 1, 2, 3), reuse=False):
+        """demon_lanes_calibrate (inputs must be resident in every lane): the rate of `steps_per_lane * k` steps on the first k lanes
+        for k = 1 .. len(group), under the stream mapping behind 0 .. max(pads) placeholder streams (the mapping of HIP streams onto
+        hardware queues depends on every stream alive in the process: the same lanes measured 3480 .. 4220 pairs/s over 0 .. 3
+        placeholders, `gpurun_out/r5m/pad.txt`).  Keeps the best (placeholders, k) among the `candidates` lane counts (default:
+        all), closes the lanes beyond k and returns {"k@placeholders": pairs/s}.  A group that keeps ONE lane turns it back into a
+        plain context (side branches on, latency plan).  reuse: a winner remembered for this process environment (mapping_key())
+        is re-applied without measuring; returns {} then."""
+        from ._lib import LanesResult
+        import ctypes
+        ks = [k for k in sorted(set(candidates or range(1, len(self.ctxs) + 1))) if 1 <= k <= len(self.ctxs)]
+        if not ks:
+            raise ValueError("candidates %r: no lane count in [1, %d]" % (candidates, len(self.ctxs)))
+        key = self.mapping_key()
+        if reuse:
+            self._cache_load()
+            hit = self._cache.get(key)
+            if hit and 1 <= hit["lanes"] <= len(self.ctxs):
+                self._keep(hit["lanes"], hit["placeholder_streams"], hit["pairs_per_s"])
+                self._apply(hit["placeholder_streams"])
+                self.mapping["reused"] = True
+                return {}
+        res = LanesResult()
+        arr, k = self._handles()
+        first = self.ctxs[0]
+        first._check(first.lib.demon_lanes_calibrate(arr, k, int(n), int(iterations), int(bool(bootstrap_only)), int(steps_per_lane),
+                                                     int(max(pads) if len(self.ctxs) > 1 and pads else 0), ctypes.byref(res)))
+        rates, best = {}, None
+        for i in range(res.ntable):
+            e = res.table[i]
+            rates["%d@%d" % (e.lanes, e.placeholder_streams)] = float(e.pairs_per_s)
+            if e.lanes in ks and (e.placeholder_streams in pads or e.placeholder_streams == 0) and (best is None or e.pairs_per_s > best[0]):
+                best = (float(e.pairs_per_s), e.lanes, e.placeholder_streams)
+        if best[2] != res.placeholder_streams:        # (the C side left the lanes on ITS winner; ours is restricted to `candidates`)
+            self._apply(best[2])
+        self._keep(best[1], best[2], best[0])
+        self._cache[key] = dict(self.mapping)
+        self._cache_store()
         return rates
 
     def next_lane(self):

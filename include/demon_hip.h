@@ -96,6 +96,7 @@ int demon_set_weights_blob_device(demon_ctx *ctx, const void *device_blob, int64
  * "tune_lanes" 1..8 (default 1): demon_autotune times every candidate as that many CONCURRENT replays on as many streams
  * ("throughput mode") -- the right cost when several passes are in flight on the GPU (demon_amd/lanes.py) */
 int demon_set_option(demon_ctx *ctx, const char *key, int value);
+int demon_get_option(const demon_ctx *ctx, const char *key, int *value);
 /* Times every applicable kernel variant (im2col / patch-staged, tile shape, split-K) of every layer at batch n on
  * this GPU and keeps the fastest per layer (~1 s; results do not change, only launch plans). */
 int demon_autotune(demon_ctx *ctx, int n);
@@ -122,6 +123,10 @@ int demon_autotune(demon_ctx *ctx, int n);
 int demon_num_layers(const demon_ctx *ctx);
 int demon_plan_get(const demon_ctx *ctx, int n, int layer_index, char *name, int name_cap, int *kind, int *tile, int *ksplit);
 int demon_plan_set(demon_ctx *ctx, int n, const char *layer_name, int kind, int tile, int ksplit);
+/* forgets every plan entry of batch size n (the layers fall back to the nearest tuned batch size / the heuristics): call it before
+ * installing ANOTHER plan for the same n, so that a layer the new plan does not mention (e.g. a kind-14 marker of the old one)
+ * does not survive the swap */
+int demon_plan_clear(demon_ctx *ctx, int n);
 
 /* ---- networks, host buffers in / host buffers out ------------------------------------------------
  * demon_bootstrap  replaces BootstrapNet.eval   (networks_original.py:60-88)
@@ -152,6 +157,35 @@ int demon_synchronize(demon_ctx *ctx);
  * DEMON_ERR_NOT_READY (nothing falls onto the null stream); demon_synchronize, demon_set_weight*, demon_plan_* still work.   */
 int demon_release_streams(demon_ctx *ctx);
 int demon_acquire_streams(demon_ctx *ctx);
+/* Lanes (several contexts = several passes in flight on ONE GPU; the reference's counterpart is a caller that loops over batches,
+ * examples/evaluation.py:225-256).  How many lanes pay off, and behind how many idle "placeholder" streams their streams must be
+ * created to land on hardware queues of their own, is MEASURED (it depends on every stream alive in the process: another
+ * library's, RCCL's, torch's):
+ *   demon_lanes_apply     : every lane releases its streams, `placeholder_streams` idle streams are created (owned by ctxs[0], freed
+ *                           with it or by the next call), the lanes acquire new streams in array order.  Nothing may be in flight.
+ *   demon_lanes_calibrate : for 0 .. max_placeholders placeholder streams and k = 1 .. nctx lanes: the rate of steps_per_lane * k
+ *                           forward passes (demon_run_full(n, iterations), or demon_run_bootstrap when bootstrap_only) fed round
+ *                           robin to the first k contexts over their RESIDENT inputs (demon_upload_inputs first), best of two
+ *                           rounds by the host clock.  Fills `result` (winner + the whole table), leaves the contexts on the
+ *                           winning stream mapping; closing the contexts beyond result->lanes is the caller's business.  A winner
+ *                           measured once can be re-applied in a later process of the same kind with demon_lanes_apply.
+ * Contexts of a group: same device, side_branches off (demon_set_option) when nctx > 1, one host thread. */
+#define DEMON_LANES_MAX 8
+#define DEMON_LANES_MAX_PLACEHOLDERS 7
+#define DEMON_LANES_TABLE_CAP 64
+typedef struct demon_lanes_entry {
+    int lanes, placeholder_streams;
+    float pairs_per_s;
+} demon_lanes_entry;
+typedef struct demon_lanes_result {
+    int lanes, placeholder_streams;   /* the winner */
+    float pairs_per_s;
+    int ntable;
+    demon_lanes_entry table[DEMON_LANES_TABLE_CAP];
+} demon_lanes_result;
+int demon_lanes_apply(demon_ctx *const *ctxs, int nctx, int placeholder_streams);
+int demon_lanes_calibrate(demon_ctx *const *ctxs, int nctx, int n, int iterations, int bootstrap_only, int steps_per_lane,
+                          int max_placeholders, demon_lanes_result *result);
 int demon_download_outputs(demon_ctx *ctx, int n, const demon_outputs *out, float *predict_depth0);
 /* Pipelining across contexts (copy / compute overlap): the _async variants only enqueue on the context's stream; the host buffers
  * must be page-locked (demon_host_register pins an existing allocation, e.g. a numpy array) and stay untouched until

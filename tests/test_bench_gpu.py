@@ -46,6 +46,14 @@ def test_bench_under_torch_distributed_run_with_the_rccl_route():
     assert rec["config"]["rccl_nranks"] == 1 and rec["config"]["weights_broadcast_route"] == "rccl"
     assert rec["outputs_finite"] is True and rec["value"] > 100
     assert abs(rec["value"] - 32 * 2 / (rec["ms_per_step"] * 2e-3)) < 1e-6 * rec["value"]
+    # every rank's own clock and lane calibration travel in the line (what makes the first 8-GPU run diagnosable)
+    pr = rec["per_rank"]
+    assert len(pr["ranks"]) == 1 and pr["ranks"][0]["rank"] == 0 and pr["lanes"] == [rec["config"]["lanes"]]
+    assert pr["pairs_per_s_min"] == pr["pairs_per_s_max"] >= rec["value"] * (1 - 1e-6)           # the reported time is the MAX over ranks
+    m = pr["ranks"][0]["lanes_mapping"]
+    assert m["lanes"] == rec["config"]["lanes"] and 0 <= m["placeholder_streams"] <= 3
+    assert pr["ranks"][0]["lanes_calibration_pairs_per_s"] == rec["config"]["lanes_calibration_pairs_per_s"]
+    assert rec["value_single_lane"] == rec["single_lane"]["pairs_per_s"] > 100
 
 
 def test_bench_default_line_has_roofline_and_host_to_host_rates():
