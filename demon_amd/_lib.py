@@ -105,6 +105,7 @@ SIGNATURES = {
     "demon_op_dense": (_I, [_P, c_float_p, c_float_p, c_float_p, c_float_p] + [_I] * 4),
     "demon_bench_layer": (_I, [_P] + [_I] * 13 + [c_float_p, ctypes.POINTER(ctypes.c_double)]),
     "demon_last_kernel": (_I, [ctypes.c_char_p, _I]),
+    "demon_debug_check_guards": (_I, [_P, c_int_p]),
 }
 
 _lib = None

@@ -33,10 +33,10 @@ __global__ __launch_bounds__(TH_NT, 4) void conv_thin_kernel(ThinArgs a)
     const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
     const int y0 = ty * TH_TY, x0 = tx * TH_TX;
     const int y_org = y0 * STRIDE - a.pad;
-    constexpr int OOB = 0x7ffffff0, NREC = 0x40000000;
+    constexpr int OOB = 0x7ffffff0;
 
     // ---- stage the patch: a thread moves 16-byte pieces (row = ci * PH + pr, 4 columns)
-    const auto irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + (long)n * a.in_n_stride + x0), 0, NREC, 0x00020000);
+    const auto irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + (long)n * a.in_n_stride + x0), 0, rsrc_bytes(view_floats_left(a.N, n, a.in_n_stride, a.Cin, 0, (long)a.H * a.W, (long)a.H * a.W) - x0), 0x00020000);
     const int nrows = a.Cin * PH;
     constexpr int MAXP = (6 * PH * 16 + TH_NT - 1) / TH_NT;   // Cin <= 6 (K <= 56)
     floatx4 pv[MAXP];
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(TH_NT, 4) void conv_thin_kernel(ThinArgs a)
     }
 
     // ---- bias, leaky relu, 16-byte stores: lane = 4 consecutive pixels of channel cb * 16 + 4 lk + r
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n * a.out_n_stride + x0, 0, NREC, 0x00020000);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n * a.out_n_stride + x0, 0, rsrc_bytes(view_floats_left(a.N, n, a.out_n_stride, a.Cout, 0, a.out_plane, (long)a.Ho * a.Wo) - x0), 0x00020000);
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int y = y0 + 2 * wave + rr;

@@ -73,8 +73,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     // no address arithmetic and no masking: operands come through buffer loads (uniform base advanced by SALU, per-thread byte
     // offsets fixed for the whole kernel, elements outside the image carry an out-of-range offset and read as zero), and every
     // LDS address of both buffers is precomputed.
-    constexpr int OOB = 0x7ffffff0;        // >= num_records of the buffer resources: reads as 0
-    constexpr int NREC = 0x40000000;
+    constexpr int OOB = 0x7ffffff0;        // >= num_records of the buffer resources (rsrc_bytes, internal.h): reads as 0
     // ---- patch loader: element e = tid + i*NT of the [G*CKS][PH][PW] patch, decoded once
     const int plane_elems = a.PH * a.PW;
     const int nelem = a.G * CKS * plane_elems;
@@ -139,8 +138,8 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     float pregA[EPT], pregB[EPT];
     floatx4 aregA[MB], aregB[MB];
     auto load_tiles = [&](float (&preg)[EPT], floatx4 (&areg)[MB], int step) {
-        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * a.H * a.W), 0, NREC, 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp + (long)step * CKS * a.Mpad), 0, NREC, 0x00020000);
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * a.H * a.W), 0, rsrc_bytes(view_floats_left(a.N, n0, a.in_n_stride, a.Cin, step * CKS, (long)a.H * a.W, (long)a.H * a.W)), 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp + (long)step * CKS * a.Mpad), 0, rsrc_bytes(4 * a.cls_w_stride - (long)step * CKS * a.Mpad), 0x00020000);   // [4 classes][Krows][Mpad]
         if (mask_last && step == a.nsteps_total - 1) {   // (uniform) channels past Cin read as zero
 #pragma unroll
             for (int i = 0; i < EPT; ++i)
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     __syncthreads();
     // stores through a buffer resource on this workgroup's corner of the output: uniform 64-bit base, one 32-bit offset per lane;
     // padding lanes, rows past the image and channels past Cout carry an out-of-range offset (dropped by the hardware)
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n0 * a.out_n_stride + (long)mc * plane, 0, 0x40000000, 0x00020000);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n0 * a.out_n_stride + (long)mc * plane, 0, rsrc_bytes(view_floats_left(a.N, n0, a.out_n_stride, a.Cout, mc, plane, (long)a.Ho * a.Wo)), 0x00020000);
     const int plane4 = 4 * (int)plane;
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {
@@ -394,7 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     constexpr int A4 = NUV * BM * KG;                  // 16-byte chunks of the weight tile
     constexpr int APER = (A4 + NT - 1) / NT;
     static_assert((KG * TN) % WM == 0 && UNITS >= 1, "bad shape");
-    constexpr int OOB = 0x7ffffff0, NREC = 0x40000000;
+    constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // As[2][ASZ], Ts[2][TSZ], one dummy 16-byte slot per thread
     TlScope tl(a.tl);
 
@@ -483,8 +482,8 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
             cs = step - ky * a.csteps;
             if (ky != cur_ky) { set_offsets(ky); cur_ky = ky; }
         }
-        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, NREC, 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + ((long)ky * NUV * a.Cin4 + (long)cs * CKS) * a.Mpad), 0, NREC, 0x00020000);
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, rsrc_bytes(view_floats_left(a.N, n0, a.in_n_stride, a.Cin, cs * CKS, HW, HW)), 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + ((long)ky * NUV * a.Cin4 + (long)cs * CKS) * a.Mpad), 0, rsrc_bytes(((long)(a.cross - ky) * NUV * a.Cin4 + kWinoWeightSlackRows - (long)cs * CKS) * a.Mpad), 0x00020000);
         // channels past Cin (last K-step of a cross tap, Cin not a multiple of 4 KG) are NOT read -- the planes behind the last channel
         // of the last image may lie behind the end of the allocation: their units load from the out-of-range offset, i.e. zeros
         auto units = [&](auto last_step) {   // (the masked form only in the K-steps that need it: no extra VALU in the others)
@@ -624,7 +623,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     // Stores go through a buffer resource on this workgroup's corner of the output (uniform 64-bit base, 32-bit offsets per lane):
     // channels past Cout, tiles past the image and padding lanes carry an out-of-range offset and are dropped by the hardware.
     const long P = (long)a.N * a.Ho * a.Wo;
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n0 * a.out_n_stride + (long)m0 * a.out_plane, 0, NREC, 0x00020000);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n0 * a.out_n_stride + (long)m0 * a.out_plane, 0, rsrc_bytes(view_floats_left(a.N, n0, a.out_n_stride, a.Cout, m0, a.out_plane, (long)a.Ho * a.Wo)), 0x00020000);
     const int plane4 = 4 * (int)a.out_plane;
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb) {

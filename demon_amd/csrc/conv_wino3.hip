@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     constexpr int ASZ = NE * CKS * BM, TSZ = NUV * CKS * TP;
     constexpr int A4 = NE * BM * KG;                           // 16-byte chunks of the weight tile
     constexpr int APER = (A4 + NT - 1) / NT;
-    constexpr int OOB = 0x7ffffff0, NREC = 0x40000000;
+    constexpr int OOB = 0x7ffffff0;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // As[2][ASZ], Ts[2][TSZ], one dummy 16-byte slot per thread
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,8 +133,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     float pregA[UNITS][PWD], pregB[UNITS][PWD];
     floatx4 aregA[APER], aregB[APER];
     auto load_tiles = [&](float (&preg)[UNITS][PWD], floatx4 (&areg)[APER], int cs) {
-        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, NREC, 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)cs * CKS * a.Mpad), 0, NREC, 0x00020000);
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, rsrc_bytes(view_floats_left(a.N, n, a.in_n_stride, a.Cin, cs * CKS, HW, HW)), 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)cs * CKS * a.Mpad), 0, rsrc_bytes(((long)NE * a.Cin4 + kWinoWeightSlackRows - (long)cs * CKS) * a.Mpad), 0x00020000);
         // channels past Cin (last K-step, Cin not a multiple of 4 KG) are NOT read -- the planes behind the last channel of the last
         // image may lie behind the end of the allocation: their units load from the out-of-range offset, i.e. zeros
         auto units = [&](auto last_step) {   // (the masked form only in the one K-step that needs it: no extra VALU in the others)
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     }
 
     // ---- epilogue: the two outputs of a tile from its NUV accumulators; lane = tile column, registers = 4 consecutive channels
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n * a.out_n_stride + (long)m0 * a.out_plane, 0, NREC, 0x00020000);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n * a.out_n_stride + (long)m0 * a.out_plane, 0, rsrc_bytes(view_floats_left(a.N, n, a.out_n_stride, a.Cout, m0, a.out_plane, (long)a.Ho * a.Wo)), 0x00020000);
     const int plane4 = 4 * (int)a.out_plane;
     const int x0 = OUT * (c0 + wn * 16 + l15);
 #pragma unroll

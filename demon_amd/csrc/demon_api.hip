@@ -158,6 +158,11 @@ struct demon_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     std::vector<void *> allocations;
+    // poison harness (tests/test_poison_gpu.py; environment DEMON_POISON_GUARD=1 at creation): every device allocation of the context
+    // sits flush between two guard zones filled with a quiet-NaN canary -- a read outside a tensor poisons the result, a write outside
+    // one is found by check_guards()
+    size_t guard_bytes = 0;
+    std::vector<std::pair<char *, size_t>> guarded;   // (raw allocation, payload bytes)
     std::map<std::string, View> buffers;
     std::vector<std::unique_ptr<Layer>> layers;
     std::vector<Variable> variables;
@@ -206,12 +211,53 @@ int fail(demon_ctx *c, int code, const std::string &msg)
     return code;
 }
 
+constexpr unsigned kGuardCanary = 0x7fc0dead;   // a quiet NaN: whatever reads it and computes with it yields NaN
+
 float *dev_alloc(demon_ctx *c, size_t bytes)
 {
     void *p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    if (!bytes) bytes = 16;
+    if (c->guard_bytes) {   // [guard | payload, flush on both sides (rounded up to 4 bytes) | guard], all of it canary until the owner writes its payload
+        const size_t g = c->guard_bytes, pay = (bytes + 3) / 4 * 4;
+        if (hipMalloc(&p, 2 * g + pay) != hipSuccess) return nullptr;
+        c->allocations.push_back(p);
+        if (hipMemsetD32((hipDeviceptr_t)p, (int)kGuardCanary, (2 * g + pay) / 4) != hipSuccess) return nullptr;
+        c->guarded.emplace_back((char *)p, pay);
+        return (float *)((char *)p + g);
+    }
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
     c->allocations.push_back(p);
     return (float *)p;
+}
+
+// number of guard zones that no longer hold the canary (0 = nothing wrote outside its tensor); `where` names the first one
+int check_guards(demon_ctx *c, std::string *where)
+{
+    int bad = 0;
+    const size_t g = c->guard_bytes;
+    if (!g) return 0;
+    std::vector<unsigned> host(g / 4);
+    for (size_t i = 0; i < c->guarded.size(); ++i)
+        for (int side = 0; side < 2; ++side) {
+            const char *zone = c->guarded[i].first + (side ? g + c->guarded[i].second : 0);
+            if (hipMemcpy(host.data(), zone, g, hipMemcpyDeviceToHost) != hipSuccess) { if (where && !bad) *where = "hipMemcpy of a guard zone failed"; return bad + 1; }
+            for (size_t w = 0; w < host.size(); ++w)
+                if (host[w] != kGuardCanary) {
+                    if (where && !bad)
+                        *where = "allocation #" + std::to_string(i) + " (" + std::to_string(c->guarded[i].second) + " bytes): word " + std::to_string(w) +
+                                 (side ? " BEHIND its end" : " of the zone IN FRONT of it") + " was overwritten";
+                    ++bad;
+                    break;
+                }
+        }
+    return bad;
+}
+
+size_t guard_bytes_from_env()
+{
+    const char *e = getenv("DEMON_POISON_GUARD");
+    if (!e || !*e || !atoi(e)) return 0;
+    return (size_t)4 << 20;   // 4 MiB on each side: more than any kernel's run-ahead (16 weight rows; 8 channel planes of a 192 x 256 map = 1.5 MiB)
 }
 
 // split-K workspace: kSplitKWorkspaceFloats of partial sums [cls][slice][Mpad][P], finished by conv_splitk_reduce
@@ -226,7 +272,8 @@ View buffer(demon_ctx *c, const std::string &key, int C, int H, int W)
     View v;
     // + 8 planes of slack: the patch kernel's last channel chunk may read (and discard) up to CKS-1 planes
     // past the last channel of the last sample
-    v.base = dev_alloc(c, sizeof(float) * ((size_t)c->max_batch * C * H * W + 8ul * H * W));
+    // (poison harness: no slack -- the tensor ends flush against the canary zone, so a kernel that USES what it reads there is found)
+    v.base = dev_alloc(c, sizeof(float) * ((size_t)c->max_batch * C * H * W + (c->guard_bytes ? 0ul : 8ul * H * W)));
     v.Ctot = C; v.c0 = 0; v.C = C; v.H = H; v.W = W;
     c->buffers[key] = v;
     return v;
@@ -310,25 +357,25 @@ bool plan_layer(demon_ctx *c, Layer *L, bool alloc_weights = true)
         }
     }
     if (L->wino1d_kind_of() >= 0 && !getenv("DEMON_NO_WINO")) {
-        const size_t nu = ((size_t)L->wino1d_cross() * wino1d_nuv(L->wino1d_kind_of()) * L->Cin4() + 16) * L->Mpad;   // + 16 rows: a K-step of KG groups reads 4 KG - 4 rows past Cin4 at most (KG <= 4), times zero inputs
+        const size_t nu = ((size_t)L->wino1d_cross() * wino1d_nuv(L->wino1d_kind_of()) * L->Cin4() + kWinoWeightSlackRows) * L->Mpad;   // + 16 rows: a K-step of KG groups reads 4 KG - 4 rows past Cin4 at most (KG <= 4), times zero inputs
         L->d_w1 = dev_alloc(c, sizeof(float) * nu);
         if (!L->d_w1 || hipMemset(L->d_w1, 0, sizeof(float) * nu) != hipSuccess) return false;
         L->w1_dirty = true;
         if (L->wino4_kind_of() >= 0) {
-            const size_t n4 = ((size_t)wino4_nuv(L->wino4_kind_of()) * L->Cin4() + 16) * L->Mpad;
+            const size_t n4 = ((size_t)wino4_nuv(L->wino4_kind_of()) * L->Cin4() + kWinoWeightSlackRows) * L->Mpad;
             L->d_w4 = dev_alloc(c, sizeof(float) * n4);
             if (!L->d_w4 || hipMemset(L->d_w4, 0, sizeof(float) * n4) != hipSuccess) return false;
             L->w4_dirty = true;
         }
         if (L->wino1d_cross() == 3 && L->in.W % 4 == 0 && L->in.W >= 32) {
-            const size_t n3 = ((size_t)3 * 6 * L->Cin4() + 16) * L->Mpad;
+            const size_t n3 = ((size_t)3 * 6 * L->Cin4() + kWinoWeightSlackRows) * L->Mpad;
             L->d_w3 = dev_alloc(c, sizeof(float) * n3);
             if (!L->d_w3 || hipMemset(L->d_w3, 0, sizeof(float) * n3) != hipSuccess) return false;
             L->w3_dirty = true;
         }
     }
     if (L->wino3_stride2() && L->in.W % 8 == 0 && L->in.W >= 64 && !getenv("DEMON_NO_WINO")) {
-        const size_t n3 = ((size_t)3 * 9 * L->Cin4() + 16) * L->Mpad;
+        const size_t n3 = ((size_t)3 * 9 * L->Cin4() + kWinoWeightSlackRows) * L->Mpad;
         L->d_w3 = dev_alloc(c, sizeof(float) * n3);
         if (!L->d_w3 || hipMemset(L->d_w3, 0, sizeof(float) * n3) != hipSuccess) return false;
         L->w3_dirty = true;
@@ -1938,6 +1985,7 @@ static int create_impl(demon_ctx **out, int device, int max_batch, int height, i
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, DEMON_ERR_HIP, "hipSetDevice failed");
     std::unique_ptr<demon_ctx> c(new demon_ctx);
     c->device = device; c->max_batch = max_batch; c->H = height; c->W = width; c->variant = variant;
+    c->guard_bytes = guard_bytes_from_env();   // poison harness: every allocation of this context between NaN canaries
     if (const char *fp = getenv("DEMON_FUSED_PAIRS")) c->opt_fused_pairs = atoi(fp) ? 1 : 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
         return fail(nullptr, DEMON_ERR_HIP, "hipStreamCreate failed");
@@ -2987,6 +3035,7 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
     demon_ctx scratch;  // owns the temporary device allocations of this call
     scratch.device = c->device;
     scratch.max_batch = n;
+    scratch.guard_bytes = guard_bytes_from_env();   // poison harness: input, output, every weight form between NaN canaries
     Layer L;
     L.kind = kind; L.Cin = cin; L.Cout = cout; L.kh = kh; L.kw = kw; L.sh = sh; L.sw = sw; L.ph = kh / 2; L.pw = kw / 2;
     L.act = lrelu;
@@ -3013,8 +3062,24 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
             hipMemcpy(out, L.out.base, sizeof(float) * (size_t)n * cout * ho * wo, hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(c, DEMON_ERR_HIP, "layer execution failed");
     }
+    if (!rc && scratch.guard_bytes) {
+        std::string where;
+        if (check_guards(&scratch, &where)) rc = fail(c, DEMON_ERR_HIP, std::string("poison harness: a kernel wrote outside its tensors (") + (g_last_kernel ? g_last_kernel : "?") + "): " + where);
+    }
     for (void *p : scratch.allocations) hipFree(p);
     return rc;
+}
+
+int demon_debug_check_guards(demon_ctx *c, int *violations)
+{
+    if (!c || !violations) return DEMON_ERR_INVALID;
+    hipSetDevice(c->device);
+    if (!c->guard_bytes) return fail(c, DEMON_ERR_INVALID, "the context was not created under DEMON_POISON_GUARD=1");
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::string where;
+    *violations = check_guards(c, &where);
+    if (*violations) c->err = "poison harness: " + where;
+    return DEMON_OK;
 }
 
 int demon_last_kernel(char *tag, int tag_cap)

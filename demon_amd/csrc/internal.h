@@ -106,6 +106,30 @@ struct KEntry {
 // Plain / separable convs: the pixel grid is the output grid.  4x4 stride-2 transposed convs run
 // as four 2x2 sub-pixel convs (gridDim.z = 4): the pixel grid is the INPUT grid and the output
 // lands at (2y+py, 2x+px).
+// ---- buffer resources carry the TRUE extent of what they address (round 5) ---------------------------------------------------------
+// The minimal-filtering / first-layer / dense kernels read and write through raw buffer resources (uniform 64-bit base, one 32-bit
+// byte offset per lane).  Until round 4 every descriptor said NUM_RECORDS = 1 GiB, so the hardware range check only ever caught the
+// deliberate out-of-range marker offsets (0x7ffffff0 = "this element is zero padding / does not exist"); a real addressing bug read
+// a neighbour tensor silently or page-faulted (it did once, in a test).  Now NUM_RECORDS = the bytes from the descriptor's base to
+// the END of the tensor view the kernel was given (last sample, last channel plane), computed from the launch arguments with scalar
+// arithmetic (a few SALU instructions per K-step, none on the vector ALU): a load past the end returns 0 and a store past the end is
+// dropped BY HARDWARE.  What one range check cannot see -- the gaps between the channel slices of a concat buffer -- is covered by
+// tests/test_poison_gpu.py (NaN-poisoned neighbours on every side).  Extents above 2 GiB clamp below the marker offsets.
+constexpr long kRsrcMaxBytes = 0x7fffffe0;       // < every out-of-range marker offset (0x7ffffff0, or-ed into valid offsets)
+__device__ __forceinline__ int rsrc_bytes(long floats)
+{
+    const long b = floats > 0 ? 4 * floats : 0;   // (a base at or past the end of the view: nothing is addressable)
+    return (int)(b < kRsrcMaxBytes ? b : kRsrcMaxBytes);
+}
+// floats from channel plane `c` of sample `n` to the end of a [N][C] x plane view with sample stride n_stride (last plane: plane_floats long)
+__device__ __forceinline__ long view_floats_left(int N, int n, long n_stride, int C, int c, long plane_stride, long plane_floats)
+{
+    return (long)(N - 1 - n) * n_stride + (long)(C - 1 - c) * plane_stride + plane_floats;
+}
+// zero rows behind the transformed weights U[planes][Cin4][Mpad] of the minimal-filtering kernels: a K-step of KG groups reads 4 KG - 4
+// rows past Cin4 at most (times zero inputs); shared by the allocation (demon_api.hip) and the descriptors' extents
+constexpr int kWinoWeightSlackRows = 16;
+
 struct ConvArgs {
     const float *in;    // input view base pointer (already offset to channel c0)
     float *out;         // output view base pointer (already offset to channel c0)

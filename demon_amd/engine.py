@@ -174,6 +174,12 @@ class DemonContext:
         self._check(self.lib.demon_get_option(self.h, key.encode(), ctypes.byref(v)))
         return int(v.value)
 
+    def check_guards(self):
+        """demon_debug_check_guards (contexts created under DEMON_POISON_GUARD=1): number of canary zones a kernel wrote into"""
+        v = ctypes.c_int()
+        self._check(self.lib.demon_debug_check_guards(self.h, ctypes.byref(v)))
+        return int(v.value), self.lib.demon_last_error(self.h).decode()
+
     def clear_plan(self, n):
         """demon_plan_clear: forgets every plan entry of batch size n (before another plan for the same n is installed)"""
         self._check(self.lib.demon_plan_clear(self.h, int(n)))

@@ -299,6 +299,14 @@ int demon_op_dense(demon_ctx *ctx, float *out, const float *in, const float *w_i
 int demon_bench_layer(demon_ctx *ctx, int kind, int n, int cin, int h, int w, int cout, int kh, int kw, int sh,
                       int sw, int tile, int ksplit, int iters, float *avg_ms, double *flops);
 
+/* Poison harness (tests/test_poison_gpu.py).  With DEMON_POISON_GUARD=1 in the environment when a context is created (or when a
+ * demon_op_conv2d / deconv4x4s2 / dense call runs), every device allocation -- activations, every weight form, workspaces -- is placed
+ * flush between two 4 MiB zones filled with a quiet-NaN canary and the activation buffers lose their slack planes: a kernel that
+ * reads outside a tensor and USES the value produces NaN, a kernel that writes outside one is found here (the layer-level
+ * entry points check by themselves and return DEMON_ERR_HIP).  *violations = guard zones that no longer hold the canary;
+ * demon_last_error names the first.  DEMON_ERR_INVALID on a context created without the switch.  Not on the reference's path. */
+int demon_debug_check_guards(demon_ctx *ctx, int *violations);
+
 /* Diagnostic: the tag of the contraction kernel the calling thread launched last (the names demon_profile_full reports, e.g.
  * "wino_deconv<16x64>+splitk", "conv_frag<128x32,v6>"); tests use it to see that a forced variant really ran.  Returns the tag
  * length (0: nothing launched yet). */

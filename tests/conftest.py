@@ -38,7 +38,12 @@ def synth_weights():
 def gpu_ctx(synth_weights):
     """A DemonContext with synthetic weights on cuda:0; fails loudly (no fallback) when the HIP path is absent."""
     from demon_amd import DemonContext
-    ctx = DemonContext(device=0, max_batch=4, height=192, width=256)
+    guard = os.environ.pop("DEMON_POISON_GUARD", None)      # (tests/test_poison_gpu.py sets it per test: the shared context stays a plain one)
+    try:
+        ctx = DemonContext(device=0, max_batch=4, height=192, width=256)
+    finally:
+        if guard is not None:
+            os.environ["DEMON_POISON_GUARD"] = guard
     ctx.set_weights(synth_weights)
     yield ctx
     ctx.close()
