@@ -78,6 +78,8 @@ if __name__ == "__main__":
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_STREAM_SETS=2"], tag="s2"))
     elif "--dbg" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_STREAM_DBG"], tag="dbg"))
+    elif "--unbounded" in sys.argv:   # round 4's 1 GiB buffer descriptors instead of the true tensor extents: A/B timing of the range check only
+        print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_RSRC_UNBOUNDED"], tag="unb"))
     elif "--timeline" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, extra_flags=["-DDEMON_TIMELINE"], tag="tl"))
     else:

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(ROW_NT, 2) void conv_row_kernel(RowArgs a)
     constexpr int UPER = (NUV * ROW_MAXC * 8 + ROW_NT - 1) / ROW_NT, PPER = (ROW_MAXC * ROW_R * 34 + ROW_NT - 1) / ROW_NT;
     const int nu4 = NUV * a.Cin4 * 8, np4 = a.Cin4 * ROW_R * 34;
     {
-        const auto ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu), 0, rsrc_bytes(((long)NUV * a.Cin4 + kWinoWeightSlackRows) * 32), 0x00020000);   // U[e][Cin4][Mpad = 32] + the slack rows
+        const auto ursrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu), 0, rsrc_bytes((NUV * a.Cin4 + kWinoWeightSlackRows) * 32), 0x00020000);   // U[e][Cin4][Mpad = 32] + the slack rows
         floatx4 uv[UPER];
 #pragma unroll
         for (int i = 0; i < UPER; ++i) {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(ROW_NT, 2) void conv_row_kernel(RowArgs a)
         const int n = tc / per_img, trem = tc - n * per_img;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
         const int y0 = ty * ROW_R, xin0 = 2 * tx * ROW_TX - 4;   // input column of patch column 0 (a multiple of 4)
-        const auto irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + (long)n * a.in_n_stride + (long)y0 * a.W), 0, rsrc_bytes(view_floats_left(a.N, n, a.in_n_stride, a.Cin, 0, (long)a.H * a.W, (long)a.H * a.W) - (long)y0 * a.W), 0x00020000);
+        const auto irsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in + (long)n * a.in_n_stride + (long)y0 * a.W), 0, rsrc_bytes(view_floats_left(a.N, n, a.in_n_stride, a.Cin, 0, (long)a.H * a.W, (long)a.H * a.W) - y0 * a.W), 0x00020000);
 #pragma unroll
         for (int i = 0; i < PPER; ++i) {
             const int gx = xin0 + pxq[i];

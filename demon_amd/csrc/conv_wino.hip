@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     floatx4 aregA[MB], aregB[MB];
     auto load_tiles = [&](float (&preg)[EPT], floatx4 (&areg)[MB], int step) {
         const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * a.H * a.W), 0, rsrc_bytes(view_floats_left(a.N, n0, a.in_n_stride, a.Cin, step * CKS, (long)a.H * a.W, (long)a.H * a.W)), 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp + (long)step * CKS * a.Mpad), 0, rsrc_bytes(4 * a.cls_w_stride - (long)step * CKS * a.Mpad), 0x00020000);   // [4 classes][Krows][Mpad]
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp + (long)step * CKS * a.Mpad), 0, rsrc_bytes(4 * (int)a.cls_w_stride - step * CKS * a.Mpad), 0x00020000);   // [4 classes][Krows][Mpad]
         if (mask_last && step == a.nsteps_total - 1) {   // (uniform) channels past Cin read as zero
 #pragma unroll
             for (int i = 0; i < EPT; ++i)
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
             if (ky != cur_ky) { set_offsets(ky); cur_ky = ky; }
         }
         const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, rsrc_bytes(view_floats_left(a.N, n0, a.in_n_stride, a.Cin, cs * CKS, HW, HW)), 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + ((long)ky * NUV * a.Cin4 + (long)cs * CKS) * a.Mpad), 0, rsrc_bytes(((long)(a.cross - ky) * NUV * a.Cin4 + kWinoWeightSlackRows - (long)cs * CKS) * a.Mpad), 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + ((long)ky * NUV * a.Cin4 + (long)cs * CKS) * a.Mpad), 0, rsrc_bytes(((a.cross - ky) * NUV * a.Cin4 + kWinoWeightSlackRows - cs * CKS) * a.Mpad), 0x00020000);
         // channels past Cin (last K-step of a cross tap, Cin not a multiple of 4 KG) are NOT read -- the planes behind the last channel
         // of the last image may lie behind the end of the allocation: their units load from the out-of-range offset, i.e. zeros
         auto units = [&](auto last_step) {   // (the masked form only in the K-steps that need it: no extra VALU in the others)

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     floatx4 aregA[APER], aregB[APER];
     auto load_tiles = [&](float (&preg)[UNITS][PWD], floatx4 (&areg)[APER], int cs) {
         const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, rsrc_bytes(view_floats_left(a.N, n, a.in_n_stride, a.Cin, cs * CKS, HW, HW)), 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)cs * CKS * a.Mpad), 0, rsrc_bytes(((long)NE * a.Cin4 + kWinoWeightSlackRows - (long)cs * CKS) * a.Mpad), 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)cs * CKS * a.Mpad), 0, rsrc_bytes((NE * a.Cin4 + kWinoWeightSlackRows - cs * CKS) * a.Mpad), 0x00020000);
         // channels past Cin (last K-step, Cin not a multiple of 4 KG) are NOT read -- the planes behind the last channel of the last
         // image may lie behind the end of the allocation: their units load from the out-of-range offset, i.e. zeros
         auto units = [&](auto last_step) {   // (the masked form only in the one K-step that needs it: no extra VALU in the others)

@@ -270,6 +270,11 @@ View buffer(demon_ctx *c, const std::string &key, int C, int H, int W)
     auto it = c->buffers.find(key);
     if (it != c->buffers.end()) return it->second;
     View v;
+    // tensors stay below 2^31 - 2^24 elements: buffer-resource extents (internal.h: rsrc_bytes) and the kernels' per-lane offsets are 32-bit
+    if ((size_t)c->max_batch * C * H * W + 8ul * H * W >= (1ul << 31) - (1ul << 24)) {
+        if (c->err.empty()) c->err = "max_batch too large: activation buffer '" + key + "' would exceed 2^31 elements";
+        return v;
+    }
     // + 8 planes of slack: the patch kernel's last channel chunk may read (and discard) up to CKS-1 planes
     // past the last channel of the last sample
     // (poison harness: no slack -- the tensor ends flush against the canary zone, so a kernel that USES what it reads there is found)

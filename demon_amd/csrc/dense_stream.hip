@@ -57,11 +57,11 @@ __global__ __launch_bounds__(DS_NT, 2) void dense_stream_kernel(DenseArgs a)
     const int my_cnt = wave == 0 ? seg_cnt[0] : (wave == 1 ? seg_cnt[1] : (wave == 2 ? seg_cnt[2] : seg_cnt[3]));
 
     // ---- weights: lane (r = l31, h = lhi) of MFMA step t of group g reads row 8 g + 2 t + h, units 4 r .. 4 r + 3 of the block
-    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wd + ((long)blockIdx.x * a.K + (long)g_begin * 8) * DS_BM), 0, rsrc_bytes((long)a.K * a.Mpad - ((long)blockIdx.x * a.K + (long)g_begin * 8) * DS_BM), 0x00020000);   // [Mpad / 128][K][128]
+    const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wd + ((long)blockIdx.x * a.K + (long)g_begin * 8) * DS_BM), 0, rsrc_bytes(a.K * a.Mpad - ((int)blockIdx.x * a.K + g_begin * 8) * DS_BM), 0x00020000);   // [Mpad / 128][K][128]
     const int a_voff = 4 * (lhi * DS_BM + 4 * l31);
     constexpr int row_bytes = 4 * DS_BM;
     // ---- activations: thread (n = tid / 8, q = tid % 8) loads x[n][32 p + 4 q .. + 3] of the 32-row segment p (= wave p's groups)
-    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long)n0 * a.x_n_stride + (long)g_begin * 8), 0, rsrc_bytes((long)(a.N - 1 - n0) * a.x_n_stride + a.K - (long)g_begin * 8), 0x00020000);
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x + (long)n0 * a.x_n_stride + (long)g_begin * 8), 0, rsrc_bytes((a.N - 1 - n0) * (int)a.x_n_stride + a.K - g_begin * 8), 0x00020000);
     const int xn = tid >> 3, xq = tid & 7;
     const int x_voff = (n0 + xn < a.N) ? 4 * (xn * (int)a.x_n_stride + 4 * xq) : OOB;
     const int xs_store = (4 * xq) * DS_XP + xn;               // + (32 p + e) * DS_XP

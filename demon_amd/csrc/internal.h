@@ -115,16 +115,27 @@ struct KEntry {
 // arithmetic (a few SALU instructions per K-step, none on the vector ALU): a load past the end returns 0 and a store past the end is
 // dropped BY HARDWARE.  What one range check cannot see -- the gaps between the channel slices of a concat buffer -- is covered by
 // tests/test_poison_gpu.py (NaN-poisoned neighbours on every side).  Extents above 2 GiB clamp below the marker offsets.
-constexpr long kRsrcMaxBytes = 0x7fffffe0;       // < every out-of-range marker offset (0x7ffffff0, or-ed into valid offsets)
-__device__ __forceinline__ int rsrc_bytes(long floats)
+constexpr int kRsrcMaxBytes = 0x7fffffe0;        // < every out-of-range marker offset (0x7ffffff0, or-ed into valid offsets)
+// `floats`: a 32-BIT count (every tensor of a context has fewer than 2^31 elements: create_impl refuses larger batches; the kernels'
+// per-lane byte offsets are 32-bit anyway).  32-bit min / max / shift stay on the scalar ALU -- a 64-bit ordered compare does not
+// exist there and would put a v_cmp_lt_i64 into the K loops, i.e. vector-ALU time the fp32 MFMAs share.
+__device__ __forceinline__ int rsrc_bytes(int floats)
 {
-    const long b = floats > 0 ? 4 * floats : 0;   // (a base at or past the end of the view: nothing is addressable)
-    return (int)(b < kRsrcMaxBytes ? b : kRsrcMaxBytes);
+#ifdef DEMON_RSRC_UNBOUNDED   // diagnostic build (python -m demon_amd.build --unbounded): round 4's 1 GiB descriptors, for A/B timing only
+    (void)floats;
+    return 0x40000000;
+#else
+    // three scalar instructions, spelled out: left to itself the compiler clamps with v_med3_i32, the descriptor word then lives in a
+    // VGPR and EVERY buffer load / store of the kernel becomes a readfirstlane "waterfall" loop
+    int b;
+    asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, 0x1ffffff8\n\ts_lshl_b32 %0, %0, 2" : "=s"(b) : "s"(floats) : "scc");   // < 0: nothing addressable; > 2 GiB: clamp below the markers
+    return b;
+#endif
 }
 // floats from channel plane `c` of sample `n` to the end of a [N][C] x plane view with sample stride n_stride (last plane: plane_floats long)
-__device__ __forceinline__ long view_floats_left(int N, int n, long n_stride, int C, int c, long plane_stride, long plane_floats)
+__device__ __forceinline__ int view_floats_left(int N, int n, long n_stride, int C, int c, long plane_stride, long plane_floats)
 {
-    return (long)(N - 1 - n) * n_stride + (long)(C - 1 - c) * plane_stride + plane_floats;
+    return (N - 1 - n) * (int)n_stride + (C - 1 - c) * (int)plane_stride + (int)plane_floats;
 }
 // zero rows behind the transformed weights U[planes][Cin4][Mpad] of the minimal-filtering kernels: a K-step of KG groups reads 4 KG - 4
 // rows past Cin4 at most (times zero inputs); shared by the allocation (demon_api.hip) and the descriptors' extents

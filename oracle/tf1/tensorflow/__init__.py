@@ -19,7 +19,8 @@ of oracle/net_ref.py (which uses PyTorch's convolutions): two independent restat
 Only the TensorFlow-1.4 API names the reference and the dump tool touch exist here, with TensorFlow 1.4's argument names
 (`keep_dims`, `num_or_size_splits`, ...); anything else raises AttributeError / TypeError, which is the point of the dry run.
 API (TensorFlow 1.4 names): float32, int32, bool, placeholder, constant, zeros_like, concat, split, slice, pad, transpose,
-reshape, norm, where, maximum, minimum, clip_by_value, stop_gradient, identity, variable_scope, get_variable_scope,
+reshape, norm, where, maximum, minimum, clip_by_value, stop_gradient, identity, reduce_sum, reduce_mean, sqrt, exp, abs, add_n,
+name_scope, variable_scope, get_variable_scope,
 global_variables, trainable_variables, global_variables_initializer, Graph, get_default_graph, reset_default_graph, Session,
 InteractiveSession, ConfigProto, GPUOptions, layers.conv2d, layers.conv2d_transpose, layers.dense, contrib.layers.flatten,
 contrib.layers.variance_scaling_initializer, image.resize_nearest_neighbor, test.is_gpu_available, train.Saver, __version__.
@@ -163,6 +164,7 @@ class Tensor(object):
     def __rsub__(self, other): return _elementwise(np.subtract, other, self)
     def __truediv__(self, other): return _elementwise(np.divide, self, other)
     def __neg__(self): return _elementwise(np.negative, self)
+    def __pow__(self, other): return _elementwise(np.power, self, other)       # x**2 (v2/losses.py:29, :50)
     def __lt__(self, other): return _elementwise(np.less, self, other, dtype=bool)
     def __le__(self, other): return _elementwise(np.less_equal, self, other, dtype=bool)
     def __gt__(self, other): return _elementwise(np.greater, self, other, dtype=bool)
@@ -513,6 +515,41 @@ def maximum(x, y, name=None):
 
 def minimum(x, y, name=None):
     return _elementwise(np.minimum, x, y)
+
+
+def _reduce(fn, input_tensor, axis, keep_dims):
+    t = _as_tensor(input_tensor)
+    return _cheap(lambda a: np.asarray(fn(a, axis=None if axis is None else (tuple(axis) if isinstance(axis, (list, tuple)) else axis), keepdims=keep_dims), np.float32), [t])
+
+
+def reduce_sum(input_tensor, axis=None, keep_dims=False, name=None, reduction_indices=None):   # (TensorFlow 1.4: keep_dims)
+    return _reduce(np.sum, input_tensor, axis if axis is not None else reduction_indices, keep_dims)
+
+
+def reduce_mean(input_tensor, axis=None, keep_dims=False, name=None, reduction_indices=None):
+    return _reduce(np.mean, input_tensor, axis if axis is not None else reduction_indices, keep_dims)
+
+
+def sqrt(x, name=None):
+    return _elementwise(np.sqrt, x)
+
+
+def exp(x, name=None):
+    return _elementwise(np.exp, x)
+
+
+def abs(x, name=None):   # noqa: A001
+    return _elementwise(np.abs, x)
+
+
+def add_n(inputs, name=None):
+    ts = [_as_tensor(t) for t in inputs]
+    return _cheap(lambda *arrays: sum(arrays[1:], arrays[0]), ts)
+
+
+@contextlib.contextmanager
+def name_scope(name, default_name=None, values=None):
+    yield name          # op names carry no meaning here; variable names come from variable_scope only (as in TensorFlow)
 
 
 def clip_by_value(t, clip_value_min, clip_value_max, name=None):

@@ -167,3 +167,64 @@ def test_reference_api_equals_the_reference_wiring(data_format, monkeypatch):
                 if getattr(ctx, "_owner", None) is session:
                     ctx.close()
                     del runtime._contexts[key]
+
+
+# ---- the ground-truth preparation / loss helpers of the v2 training code ------------------------------
+# tests/golden/wiring_losses.npz = the reference's own v2/losses.py:23-104, :312-374 executed on oracle/tf1 (make_golden_losses.py)
+class _OracleSops:
+    """demon_amd/sops.py's interface with oracle/ops_ref.py behind it: lets the CPU suite hold demon_amd/losses.py's WIRING to the
+    reference's (which op on which level of the pyramid, one scale_invariant_gradient call per delta, NaN replacement, channel
+    pairs of the gradient loss) without a GPU"""
+
+    def __getattr__(self, name):
+        from oracle import ops_ref
+        if name == "_ctx":
+            return lambda: self
+        if name == "depth_to_flow":
+            return lambda depth, intrinsics, rotation, translation, rotation_format="angleaxis3", inverse_depth=False, normalize_flow=False, name=None: \
+                ops_ref.depth_to_flow(depth, intrinsics, rotation, translation, inverse_depth, normalize_flow)
+        if name == "scale_invariant_gradient":
+            return lambda input, deltas=(1,), weights=(1.0,), epsilon=0.001: ops_ref.scale_invariant_gradient(input, deltas, weights, epsilon)
+        return getattr(ops_ref, name)
+
+
+def _losses_inputs():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_losses
+    return make_golden_losses.inputs()
+
+
+def _check_losses(L, tol):
+    f = np.load(os.path.join(ROOT, "tests", "golden", "wiring_losses.npz"))
+    assert "reference v2/losses.py" in str(f["backend"])
+    x = _losses_inputs()
+    got = dict(("gt/" + k, v) for k, v in L.prepare_ground_truth_tensors(x["depth"], x["rotation"], x["translation"], x["intrinsics"]).items())
+    got["pointwise_l2_loss/nchw"] = L.pointwise_l2_loss(x["pred"], x["gt"], 0.01)
+    got["pointwise_l2_loss/nhwc"] = L.pointwise_l2_loss(x["pred"].transpose(0, 2, 3, 1), x["gt"].transpose(0, 2, 3, 1), 0.01, data_format="NHWC")
+    got["scale_invariant_gradient_loss"] = L.scale_invariant_gradient_loss(x["pred"], x["gt"], 0.01)
+    got["compute_confidence_map"] = L.compute_confidence_map(x["flow_p"], x["flow_g"], scale=2)
+    got["scale_invariant_gradient"] = L.scale_invariant_gradient(x["flow_p"], deltas=[1, 2, 4], weights=[1, 0.5, 0.25], epsilon=0.001)
+    checked = 0
+    for k in f.files:
+        if k in ("backend", "l1_loss"):        # (l1_loss, v2/losses.py:23-29, has no caller in the reference and no mirror here)
+            continue
+        want, have = f[k], np.asarray(got[k], np.float32)
+        assert have.shape == want.shape, (k, have.shape, want.shape)
+        nan_w, nan_h = np.isnan(want), np.isnan(have)
+        assert np.array_equal(nan_w, nan_h), "%s: NaN pattern differs at %d positions" % (k, int((nan_w != nan_h).sum()))
+        ok = ~nan_w
+        np.testing.assert_allclose(have[ok], want[ok], rtol=tol, atol=tol, err_msg=k)
+        checked += 1
+    assert checked == 15
+
+
+def test_losses_mirror_is_wired_like_the_reference(monkeypatch):
+    from demon_amd import losses
+    monkeypatch.setattr(losses, "sops", _OracleSops())
+    _check_losses(losses, 1e-6)
+
+
+@pytest.mark.gpu
+def test_losses_on_the_hip_ops_equal_the_reference_wiring():
+    from demon_amd import losses
+    _check_losses(losses, 2e-5)
