@@ -128,6 +128,7 @@ __device__ __forceinline__ int rsrc_bytes(int floats)
     // three scalar instructions, spelled out: left to itself the compiler clamps with v_med3_i32, the descriptor word then lives in a
     // VGPR and EVERY buffer load / store of the kernel becomes a readfirstlane "waterfall" loop
     int b;
+    floats = __builtin_amdgcn_readfirstlane(floats);   // (wave-uniform by construction; an "s" operand the compiler keeps in a VGPR would not assemble)
     asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, 0x1ffffff8\n\ts_lshl_b32 %0, %0, 2" : "=s"(b) : "s"(floats) : "scc");   // < 0: nothing addressable; > 2 GiB: clamp below the markers
     return b;
 #endif
