@@ -167,6 +167,7 @@ def main():
                     help="contexts per GPU the steps go round (each with its own stream, arena, resident batch and hipGraph): that many "
                          "steps are in flight at a time.  Default 0 = measure 1 .. 5 lanes at start-up (untimed set-up) and keep the best; "
                          "1 = one step at a time")
+    ap.add_argument("--max-lanes", type=int, default=5, help="--lanes 0: the largest lane count the start-up calibration tries")
     args = ap.parse_args()
 
     import torch
@@ -177,7 +178,7 @@ def main():
         args.batch = def_batch
     auto_lanes = args.lanes <= 0
     if auto_lanes:
-        args.lanes = 3 if args.workload == "hires" else 5
+        args.lanes = 3 if args.workload == "hires" else args.max_lanes
     boot_only = args.workload == "bootstrap"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -127,6 +127,10 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
 #pragma unroll
     for (int i = 0; i < EPT; ++i) asm volatile("" : "+v"(lds_p[1][i]));
 
+    // extents of the two operand streams from THIS workgroup's base (clamped once, internal.h: rsrc_bytes); a K-step only subtracts its advance
+    const int in_bytes0 = rsrc_bytes(view_floats_left(a.N, n0, a.in_n_stride, a.Cin, 0, (long)a.H * a.W, (long)a.H * a.W));
+    const int w_bytes0 = rsrc_bytes(4 * (int)a.cls_w_stride);   // [4 classes][Krows][Mpad]
+
     floatx4 acc[MB][TN][9];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     float pregA[EPT], pregB[EPT];
     floatx4 aregA[MB], aregB[MB];
     auto load_tiles = [&](float (&preg)[EPT], floatx4 (&areg)[MB], int step) {
-        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * a.H * a.W), 0, rsrc_bytes(view_floats_left(a.N, n0, a.in_n_stride, a.Cin, step * CKS, (long)a.H * a.W, (long)a.H * a.W)), 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp + (long)step * CKS * a.Mpad), 0, rsrc_bytes(4 * (int)a.cls_w_stride - step * CKS * a.Mpad), 0x00020000);   // [4 classes][Krows][Mpad]
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)step * CKS * a.H * a.W), 0, in_bytes0 - 4 * step * CKS * a.H * a.W, 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp + (long)step * CKS * a.Mpad), 0, w_bytes0 - 4 * step * CKS * a.Mpad, 0x00020000);
         if (mask_last && step == a.nsteps_total - 1) {   // (uniform) channels past Cin read as zero
 #pragma unroll
             for (int i = 0; i < EPT; ++i)
@@ -465,6 +469,10 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
     asm volatile("" : "+v"(ra[1]));
     asm volatile("" : "+v"(rt[1]));
 
+    // extents of the two operand streams from THIS workgroup's base (clamped once, internal.h: rsrc_bytes); a K-step only subtracts its advance
+    const int in_bytes0 = rsrc_bytes(view_floats_left(a.N, n0, a.in_n_stride, a.Cin, 0, HW, HW));
+    const int w_bytes0 = rsrc_bytes((a.cross * NUV * a.Cin4 + kWinoWeightSlackRows) * a.Mpad);
+
     floatx4 acc[TN][NUV];
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb)
@@ -482,8 +490,8 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
             cs = step - ky * a.csteps;
             if (ky != cur_ky) { set_offsets(ky); cur_ky = ky; }
         }
-        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, rsrc_bytes(view_floats_left(a.N, n0, a.in_n_stride, a.Cin, cs * CKS, HW, HW)), 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + ((long)ky * NUV * a.Cin4 + (long)cs * CKS) * a.Mpad), 0, rsrc_bytes(((a.cross - ky) * NUV * a.Cin4 + kWinoWeightSlackRows - cs * CKS) * a.Mpad), 0x00020000);
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, in_bytes0 - 4 * cs * CKS * HW, 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + ((long)ky * NUV * a.Cin4 + (long)cs * CKS) * a.Mpad), 0, w_bytes0 - 4 * (ky * NUV * a.Cin4 + cs * CKS) * a.Mpad, 0x00020000);
         // channels past Cin (last K-step of a cross tap, Cin not a multiple of 4 KG) are NOT read -- the planes behind the last channel
         // of the last image may lie behind the end of the allocation: their units load from the out-of-range offset, i.e. zeros
         auto units = [&](auto last_step) {   // (the masked form only in the K-steps that need it: no extra VALU in the others)

@@ -123,6 +123,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     asm volatile("" : "+v"(ra[1]));
     asm volatile("" : "+v"(rt[1]));
 
+    // extents of the two operand streams from THIS workgroup's base (clamped once, internal.h: rsrc_bytes); a K-step only subtracts its advance
+    const int in_bytes0 = rsrc_bytes(view_floats_left(a.N, n, a.in_n_stride, a.Cin, 0, HW, HW));
+    const int w_bytes0 = rsrc_bytes((NE * a.Cin4 + kWinoWeightSlackRows) * a.Mpad);
+
     floatx4 acc[TN][NUV];
 #pragma unroll
     for (int tb = 0; tb < TN; ++tb)
@@ -133,8 +137,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
     float pregA[UNITS][PWD], pregB[UNITS][PWD];
     floatx4 aregA[APER], aregB[APER];
     auto load_tiles = [&](float (&preg)[UNITS][PWD], floatx4 (&areg)[APER], int cs) {
-        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, rsrc_bytes(view_floats_left(a.N, n, a.in_n_stride, a.Cin, cs * CKS, HW, HW)), 0x00020000);
-        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)cs * CKS * a.Mpad), 0, rsrc_bytes((NE * a.Cin4 + kWinoWeightSlackRows - cs * CKS) * a.Mpad), 0x00020000);
+        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + (long)cs * CKS * HW), 0, in_bytes0 - 4 * cs * CKS * HW, 0x00020000);
+        const auto arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wu + (long)cs * CKS * a.Mpad), 0, w_bytes0 - 4 * cs * CKS * a.Mpad, 0x00020000);
         // channels past Cin (last K-step, Cin not a multiple of 4 KG) are NOT read -- the planes behind the last channel of the last
         // image may lie behind the end of the allocation: their units load from the out-of-range offset, i.e. zeros
         auto units = [&](auto last_step) {   // (the masked form only in the one K-step that needs it: no extra VALU in the others)

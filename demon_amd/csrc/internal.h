@@ -114,7 +114,10 @@ struct KEntry {
 // the END of the tensor view the kernel was given (last sample, last channel plane), computed from the launch arguments with scalar
 // arithmetic (a few SALU instructions per K-step, none on the vector ALU): a load past the end returns 0 and a store past the end is
 // dropped BY HARDWARE.  What one range check cannot see -- the gaps between the channel slices of a concat buffer -- is covered by
-// tests/test_poison_gpu.py (NaN-poisoned neighbours on every side).  Extents above 2 GiB clamp below the marker offsets.
+// tests/test_poison_gpu.py (NaN-poisoned neighbours on every side).  Extents above 2 GiB clamp below the marker offsets.  K loops
+// clamp the extent at THEIR base once and subtract a step's advance per step (one s_mul + one s_sub beside the base update):
+// sound because a workgroup's valid offsets (within one sample / one weight array) plus that advance stay far below the clamp.
+// A/B on one box against 1 GiB descriptors (python -m demon_amd.build --unbounded, tools/rounds/r5_call2.sh): see DESIGN.md section 5.
 constexpr int kRsrcMaxBytes = 0x7fffffe0;        // < every out-of-range marker offset (0x7ffffff0, or-ed into valid offsets)
 // `floats`: a 32-BIT count (every tensor of a context has fewer than 2^31 elements: create_impl refuses larger batches; the kernels'
 // per-lane byte offsets are 32-bit anyway).  32-bit min / max / shift stay on the scalar ALU -- a 64-bit ordered compare does not
