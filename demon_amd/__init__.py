@@ -4,6 +4,19 @@ The numeric work lives in libdemon_hip.so (demon_amd/csrc, C ABI in include/demo
 the thin host side: ctypes binding, weight table / IO, and mirrors of the reference interfaces
 `depthmotionnet.networks_original` and `lmbspecialops`.
 """
-from .engine import DemonContext, DemonError  # noqa: F401
-from .runtime import get_context, set_default_weights, default_weights  # noqa: F401
-from . import weights  # noqa: F401
+import os as _os
+
+# Hardware queues.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two busy
+# lanes (demon_amd/lanes.py) that share one serialise.  Measured on an MI355X at batch 32 (round 5, gpurun_out/r5c/ab.txt, one box):
+# 4 queues -> best 3 lanes, 4 488 - 4 499 pairs/s;  8 queues -> best 4 lanes, 4 622 - 4 640 (+3 %);  5 / 6 / 10 / 12 / 16 queues and
+# 5 - 6 lanes: no gain.  The runtime reads the variable when it initialises (first HIP call of the process), so it is set here, at
+# import, unless the caller already chose a value; DEMON_HW_QUEUES=0 leaves the runtime's default alone.  A C / C++ host sets
+# GPU_MAX_HW_QUEUES=8 in its own environment (INTEGRATION.md section 6).
+_q = _os.environ.get("DEMON_HW_QUEUES", "8")
+if _q not in ("", "0"):
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", _q)
+del _q
+
+from .engine import DemonContext, DemonError  # noqa: F401,E402
+from .runtime import get_context, set_default_weights, default_weights  # noqa: F401,E402
+from . import weights  # noqa: F401,E402
