@@ -179,7 +179,6 @@ struct demon_ctx {
     std::vector<hipStream_t> tune_streams;   // throughput-mode autotune (option tune_lanes): concurrent replays need streams of their own
     std::vector<hipEvent_t> tune_events;
     int opt_tune_lanes = 1;
-    int stream_priority = 0;   // experiment hook (DEMON_LANE_PRIORITIES=1, demon_lanes_apply): 0 = default, else the HIP stream priority of this lane's streams
     std::vector<hipStream_t> placeholder_streams;   // demon_lanes_apply / demon_lanes_calibrate: idle streams that shift the lanes' stream -> hardware-queue mapping (owned by lane 0)
     std::vector<hipEvent_t> events;  // fork / join events, one per use inside a sequence
     int opt_side_branches = 1;
@@ -2627,10 +2626,7 @@ int demon_acquire_streams(demon_ctx *c)
 {
     if (!c) return DEMON_ERR_INVALID;
     hipSetDevice(c->device);
-    if (!c->stream) {
-        if (c->stream_priority) HIP_TRY(c, hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, c->stream_priority));
-        else HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    }
+    if (!c->stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (!c->side_stream && c->variant != 0 && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) {
         c->side_stream = nullptr;
         c->opt_side_branches = 0;
@@ -2670,18 +2666,8 @@ int demon_lanes_apply(demon_ctx *const *ctxs, int nctx, int placeholder_streams)
         HIP_TRY(c0, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         c0->placeholder_streams.push_back(st);
     }
-    // experiment hook: DEMON_LANE_PRIORITIES=1 gives lane i the stream priority (greatest, default, least)[i % 3]
-    static const int prio_mode = getenv("DEMON_LANE_PRIORITIES") ? atoi(getenv("DEMON_LANE_PRIORITIES")) : 0;
-    int least = 0, greatest = 0;
-    if (prio_mode) hipDeviceGetStreamPriorityRange(&least, &greatest);
-    for (int i = 0; i < nctx; ++i) {
-        if (prio_mode) {
-            const int cls = i % 3;
-            ctxs[i]->stream_priority = cls == 0 ? greatest : (cls == 2 ? least : 0);
-            if (prio_mode == 2) ctxs[i]->stream_priority = i == 0 ? greatest : least;   // one leader, the rest fill in
-        }
+    for (int i = 0; i < nctx; ++i)
         if ((r = demon_acquire_streams(ctxs[i]))) return r == DEMON_ERR_HIP ? fail(c0, r, "lane " + std::to_string(i) + ": " + ctxs[i]->err) : r;
-    }
     return DEMON_OK;
 }
 

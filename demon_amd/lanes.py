@@ -52,8 +52,7 @@ class LaneGroup:
                 c.set_plan(self._plan_batch, plan)
             self.ctxs.append(c)
         self._requested = lanes
-        import os
-        self._side_off = lanes > 1 and os.environ.get("DEMON_LANES_SIDE_BRANCHES", "0") != "1"   # (the switch is an experiment hook: see the module header)
+        self._side_off = lanes > 1
         if self._side_off:
             for c in self.ctxs:
                 c.set_option("side_branches", 0)
