@@ -12,7 +12,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # rocprofv3 passes: the headline's kernels (throughput-mode plan) ONE PASS AT A TIME -- counter collection serialises kernels anyway, and
 # the per-kernel durations of the trace are then comparable with bench.py's own per-launch hip-event times (which are taken one
 # launch after the other); stats_lanes = the default command (3 passes in flight: kernel durations overlap and stretch)
-B="python bench.py --no-cpu-baseline --no-e2e --no-roofline --lanes 1 --plan-lanes 3"
+PL=${PLAN_LANES:-4}
+B="python bench.py --no-cpu-baseline --no-e2e --no-roofline --lanes 1 --plan-lanes $PL"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- $B > $out/stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_lanes -o p -- python bench.py --no-cpu-baseline --no-e2e --no-roofline > $out/stats_lanes.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- $B > $out/pmc_fetch.log 2>&1
@@ -26,7 +27,23 @@ for spec in "config1_bootstrap:--workload bootstrap" "batch1:--batch 1" "batch8:
   name=${spec%%:*}; args=${spec#*:}
   timeout 400 python bench.py $args --no-cpu-baseline > $out/bench_$name.json 2> $out/layers_$name.txt
 done
-timeout 200 python tools/throughput_profile.py > $out/throughput_profile.txt 2> $out/throughput_profile.err
+timeout 200 python tools/throughput_profile.py --lanes $PL > $out/throughput_profile.txt 2> $out/throughput_profile.err
+# 5. what each group of layers costs with the headline's passes in flight
+timeout 400 python tools/ablate_lanes.py --lanes $PL > $out/ablate_lanes.txt 2> $out/ablate_lanes.err
+cp $out/ablate_lanes.txt profiles/${tag}_ablate_lanes.txt
+# 6. BASELINE configs[4] evidence (640x480, "HBM-bound warp2d stress, rocprof GB/s"): counters + durations of the same command
+H="python bench.py --workload hires --no-cpu-baseline --no-e2e --no-roofline --lanes 1 --steps 4 --warmup 2"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/hires_stats -o p -- $H > $out/hires_stats.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/hires_fetch -o p -- $H > $out/hires_fetch.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/hires_write -o p -- $H > $out/hires_write.log 2>&1
+python tools/hires_counters.py $out/hires_fetch $out/hires_write $out/hires_stats profiles/${tag}_hires_counters.json > $out/hires_counters.log 2>&1
+find $out/hires_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} profiles/${tag}_hires_kernel_stats.csv
+# 7. the RCCL route as the driver launches a rank, and the whole -m gpu suite with the reasons of its skips
+DEMON_FORCE_DIST=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 1 --no-cpu-baseline --no-roofline --no-e2e > $out/forcedist.out 2> $out/forcedist.err
+grep "^{" $out/forcedist.out | tail -1 > profiles/${tag}_forcedist_rccl_1rank.json
+timeout 1500 python -m pytest tests -m gpu -q -rs -p no:cacheprovider > $out/gputest_rs.log 2>&1; echo "pytest rc $?" >> $out/gputest_rs.log
+cp $out/gputest_rs.log profiles/${tag}_gputest_rs.log
+mkdir -p $out/profiles_on_box && cp profiles/${tag}_* $out/profiles_on_box/
 # keep what travels back small: the per-dispatch traces are large
 find $out -name "*kernel_trace.csv" -size +20M -delete
 ls -la $out $out/stats/* | head -40

@@ -8,7 +8,7 @@ import numpy as np
 from demon_amd import DemonContext, weights as W
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--lanes", type=int, default=3)
+ap.add_argument("--lanes", type=int, default=4)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--version", type=int, default=1)
 args = ap.parse_args()
