@@ -2376,6 +2376,10 @@ int demon_set_option(demon_ctx *c, const char *key, int value)
     if (!strcmp(key, "tune_lanes")) {
         if (value < 1 || value > 8) return fail(c, DEMON_ERR_INVALID, "tune_lanes must be in [1, 8]");
         c->opt_tune_lanes = value;
+        if (value == 1) {   // back to one pass at a time: the extra streams of the concurrent replays go (they take part in the stream -> queue mapping)
+            for (hipStream_t st : c->tune_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
+            c->tune_streams.clear();
+        }
         return DEMON_OK;
     }
     if (!strcmp(key, "side_branches")) { c->opt_side_branches = (value && c->side_stream && c->d_ws_side != c->d_ws) ? 1 : 0; return DEMON_OK; }
@@ -2609,13 +2613,18 @@ int demon_synchronize(demon_ctx *c)
 // The runtime binds a HIP stream to one of a few hardware queues when the stream is created, by a rule that depends on every stream
 // alive in the process; two busy streams on one queue serialise.  A lane group (demon_amd/lanes.py) that measures a poor mapping
 // gives its streams back (demon_release_streams on every lane), optionally creates a few placeholder streams, and takes new ones
-// (demon_acquire_streams, lane by lane).  Captured hipGraphs stay valid: a graph exec is not tied to the stream it was captured on.
+// (demon_acquire_streams, lane by lane).  Cached hipGraph execs are dropped and captured again on the new streams at the next run call.
 int demon_release_streams(demon_ctx *c)
 {
     if (!c) return DEMON_ERR_INVALID;
     hipSetDevice(c->device);
     if (c->stream) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipStreamDestroy(c->stream)); c->stream = nullptr; }
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); c->side_stream = nullptr; }
+    // graph execs captured across BOTH streams (side branches) do not survive the streams they were captured on: launching one after
+    // the exchange aborted inside the HIP runtime ("pure virtual method called", round 5, tools/e2e_bisect.py).  All cached execs go;
+    // the next run call captures again on the new streams (a few milliseconds, set-up time like the exchange itself).
+    for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+    c->graphs.clear();
     // the throughput-mode tuner's streams take part in the stream -> hardware-queue mapping as well (re-created on demand)
     for (hipStream_t st : c->tune_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
     c->tune_streams.clear();

@@ -152,7 +152,8 @@ int demon_synchronize(demon_ctx *ctx);
 /* Stream <-> hardware-queue mapping: the HIP runtime binds a stream to one of a few hardware queues at creation, by a rule that
  * depends on every stream alive in the process, and two busy streams on one queue serialise.  A group of contexts that measures a
  * poor mapping (demon_amd/lanes.py: LaneGroup.calibrate) releases all its streams, optionally creates placeholder streams
- * (demon_create_ops contexts), and acquires new ones context by context.  Nothing may be in flight; captured graphs stay valid.
+ * (demon_create_ops contexts), and acquires new ones context by context.  Nothing may be in flight; cached hipGraph execs are dropped
+ * (a graph captured across a context's two streams does not survive them) and captured again at the next run call.
  * Between release and acquire the context must not be used: every entry point that would enqueue work returns
  * DEMON_ERR_NOT_READY (nothing falls onto the null stream); demon_synchronize, demon_set_weight*, demon_plan_* still work.   */
 int demon_release_streams(demon_ctx *ctx);

@@ -175,3 +175,16 @@ def test_pmc_family_covers_every_contraction_kernel():
         assert any(k + "<" in open(os.path.join(ROOT, "demon_amd", "csrc", f)).read() or k + "(" in open(os.path.join(ROOT, "demon_amd", "csrc", f)).read()
                    for f in os.listdir(os.path.join(ROOT, "demon_amd", "csrc")) if f.endswith(".hip")), k
 
+
+
+def test_package_import_sets_the_hardware_queue_count():
+    """demon_amd/__init__.py: GPU_MAX_HW_QUEUES=8 unless the caller chose a value or opted out (the HIP runtime reads it at its first call)"""
+    import subprocess
+    import sys
+    code = "import os; import demon_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for env_extra, want in (({}, "8"), ({"GPU_MAX_HW_QUEUES": "4"}, "4"), ({"DEMON_HW_QUEUES": "0"}, "None"), ({"DEMON_HW_QUEUES": "6"}, "6")):
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "DEMON_HW_QUEUES")}
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.strip() == want, (env_extra, r.stdout, r.stderr[-500:])

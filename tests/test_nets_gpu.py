@@ -545,7 +545,7 @@ def test_lane_group_calibration_keeps_results(synth_weights):
 def test_released_streams_refuse_work(synth_weights):
     """demon_release_streams / demon_acquire_streams (include/demon_hip.h): between the two a context has no HIP stream; every entry
     point that would enqueue work must refuse (DEMON_ERR_NOT_READY) instead of falling onto the null stream, and after acquiring
-    new streams the context computes what it computed before (its captured hipGraph survives)."""
+    new streams the context computes what it computed before (its hipGraph is captured again on the new streams: a graph captured across the two streams of a context does not survive them)."""
     from demon_amd import DemonContext
     from demon_amd.engine import DemonError
     n = 1
@@ -564,5 +564,34 @@ def test_released_streams_refuse_work(synth_weights):
         got = ctx.full(pair, img2_2, iterations=1)
         for k in want:
             np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    finally:
+        ctx.close()
+
+
+def test_borrowed_context_works_after_the_lane_group_is_closed(synth_weights):
+    """A context that ran with side branches (a graph captured across its two streams), became lane 0 of a group (streams exchanged by
+    the calibration, side branches off) and got back on its own must compute what it computed before -- round 5: launching the graph
+    exec captured before the exchange aborted inside the HIP runtime; demon_release_streams now drops the cached execs."""
+    from demon_amd import DemonContext
+    from demon_amd.lanes import LaneGroup
+    n = 2
+    ctx = DemonContext(0, n, 192, 256)
+    try:
+        ctx.set_weights(synth_weights)
+        pair, img2_2 = make_inputs(n, seed=81)
+        want = ctx.full(pair, img2_2, iterations=2)                 # side branches on: graph across both streams
+        group = LaneGroup(first=ctx, lanes=3, batch=n)
+        try:
+            for c in group.ctxs:
+                c.upload_inputs(pair, img2_2)
+            mid = ctx.full(pair, img2_2, iterations=2)              # side branches off inside the group
+            group.calibrate(n, iterations=2, steps_per_lane=2, pads=(0, 1))
+        finally:
+            group.close()
+        assert ctx.get_option("side_branches") == 1
+        got = ctx.full(pair, img2_2, iterations=2)                  # the pre-group graph key again
+        for k in want:
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+            np.testing.assert_array_equal(mid[k], want[k], err_msg=k)
     finally:
         ctx.close()
