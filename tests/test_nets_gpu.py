@@ -595,3 +595,50 @@ def test_borrowed_context_works_after_the_lane_group_is_closed(synth_weights):
             np.testing.assert_array_equal(mid[k], want[k], err_msg=k)
     finally:
         ctx.close()
+
+
+def test_lane_calibration_winner_is_remembered_per_environment(synth_weights, tmp_path, monkeypatch):
+    """LaneGroup.calibrate(reuse=True): the (lanes, placeholder streams) winner of one group is re-applied by the next group of the same
+    process environment (mapping_key) through demon_lanes_apply, without measuring -- also across processes through $DEMON_LANES_CACHE --
+    and the lanes compute what an uncalibrated context computes"""
+    import json
+    from demon_amd import DemonContext
+    from demon_amd.lanes import LaneGroup
+    n = 2
+    cache = tmp_path / "lanes.json"
+    monkeypatch.setenv("DEMON_LANES_CACHE", str(cache))
+    monkeypatch.setattr(LaneGroup, "_cache", {})
+    batches = [make_inputs(n, seed=50 + i) for i in range(3)]
+    g1 = LaneGroup(synth_weights, lanes=3, batch=n)
+    try:
+        g1.upload_inputs(batches)
+        rates = g1.calibrate(n, iterations=1, steps_per_lane=2, pads=(0, 1), reuse=True)     # nothing remembered yet: measures
+        assert rates and "reused" not in g1.mapping
+        won = dict(g1.mapping)
+        key = g1.mapping_key()
+    finally:
+        g1.close()
+    assert json.loads(cache.read_text())[key]["lanes"] == won["lanes"]
+    monkeypatch.setattr(LaneGroup, "_cache", {})                                              # "another process": only the file is left
+    g2 = LaneGroup(synth_weights, lanes=3, batch=n)
+    try:
+        g2.upload_inputs(batches)
+        assert g2.calibrate(n, iterations=1, steps_per_lane=2, pads=(0, 1), reuse=True) == {}
+        assert g2.mapping["reused"] is True and g2.mapping["lanes"] == won["lanes"] == len(g2)
+        assert g2.mapping["placeholder_streams"] == won["placeholder_streams"]
+        g2.run_resident(n, 2 * len(g2), iterations=1)
+        g2.synchronize()
+        got = g2.ctxs[0].download_outputs(n)
+    finally:
+        g2.close()
+    plain = DemonContext(0, n, 192, 256)
+    try:
+        plain.set_weights(synth_weights)
+        plain.load_tuned_plan(n, lanes=3 if won["lanes"] > 1 else 1)
+        if won["lanes"] > 1:
+            plain.set_option("side_branches", 0)
+        want = plain.full(*batches[0], iterations=1)
+    finally:
+        plain.close()
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
