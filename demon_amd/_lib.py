@@ -26,8 +26,8 @@ class LanesEntry(ctypes.Structure):
 
 class LanesResult(ctypes.Structure):
     """demon_lanes_result (DEMON_LANES_TABLE_CAP = 64)"""
-    _fields_ = [("lanes", ctypes.c_int), ("placeholder_streams", ctypes.c_int), ("pairs_per_s", ctypes.c_float), ("ntable", ctypes.c_int),
-                ("table", LanesEntry * 64)]
+    _fields_ = [("lanes", ctypes.c_int), ("placeholder_streams", ctypes.c_int), ("pairs_per_s", ctypes.c_float),
+                ("verified_pairs_per_s", ctypes.c_float), ("attempts", ctypes.c_int), ("ntable", ctypes.c_int), ("table", LanesEntry * 64)]
 
 
 class LaunchRecord(ctypes.Structure):
@@ -67,7 +67,7 @@ SIGNATURES = {
     "demon_get_option": (_I, [_P, ctypes.c_char_p, c_int_p]),
     "demon_plan_clear": (_I, [_P, _I]),
     "demon_lanes_apply": (_I, [ctypes.POINTER(_P), _I, _I]),
-    "demon_lanes_calibrate": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I, _I, _I, ctypes.POINTER(LanesResult)]),
+    "demon_lanes_calibrate": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I, _I, _I, ctypes.c_uint, ctypes.POINTER(LanesResult)]),
     "demon_autotune": (_I, [_P, _I]),
     "demon_num_layers": (_I, [_P]),
     "demon_plan_get": (_I, [_P, _I, _I, ctypes.c_char_p, _I, c_int_p, c_int_p, c_int_p]),

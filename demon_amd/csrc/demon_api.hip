@@ -2681,7 +2681,7 @@ int demon_lanes_apply(demon_ctx *const *ctxs, int nctx, int placeholder_streams)
 }
 
 int demon_lanes_calibrate(demon_ctx *const *ctxs, int nctx, int n, int iterations, int bootstrap_only, int steps_per_lane,
-                          int max_placeholders, demon_lanes_result *res)
+                          int max_placeholders, unsigned lanes_mask, demon_lanes_result *res)
 {
     int r = lanes_check(ctxs, nctx);
     if (r) return r;
@@ -2734,10 +2734,38 @@ int demon_lanes_calibrate(demon_ctx *const *ctxs, int nctx, int n, int iteration
                 res->table[res->ntable].pairs_per_s = v;
                 ++res->ntable;
             }
-            if (v > res->pairs_per_s) { res->pairs_per_s = v; res->lanes = k; res->placeholder_streams = pad; }
+            const bool allowed = !lanes_mask || ((lanes_mask >> k) & 1u);   // (the whole table is measured; the winner comes from the allowed lane counts)
+            if (allowed && v > res->pairs_per_s) { res->pairs_per_s = v; res->lanes = k; res->placeholder_streams = pad; }
         }
     }
-    if (res->placeholder_streams != current && (r = demon_lanes_apply(ctxs, nctx, res->placeholder_streams))) return r;
+    if (res->pairs_per_s < 0.0f) return fail(c0, DEMON_ERR_INVALID, "lanes_mask allows no lane count in [1, nctx]");
+    // Back to the winner -- and MEASURE it again there.  Which hardware queue a new stream gets also depends on how many streams the
+    // process created before (round 5, under torch.distributed.run: the cell that measured 4 718 pairs/s ran 4 119 after it was simply
+    // applied again, gpurun_out/r5h_verify.txt), so the placeholder count alone does not reproduce a mapping.  Apply, measure, and when
+    // the rate is not the winner's, shift the creation count by one throw-away stream and try again; the state that is left is one
+    // that was measured.
+    res->verified_pairs_per_s = res->pairs_per_s;
+    if (nctx > 1) {
+        float best_seen = -1.0f;
+        for (res->attempts = 1; res->attempts <= DEMON_LANES_MAX_ATTEMPTS; ++res->attempts) {
+            if (res->attempts > 1 || res->placeholder_streams != current) {
+                if (res->attempts > 1) {
+                    hipStream_t burn = nullptr;
+                    if (hipStreamCreateWithFlags(&burn, hipStreamNonBlocking) == hipSuccess) hipStreamDestroy(burn);
+                }
+                if ((r = demon_lanes_apply(ctxs, nctx, res->placeholder_streams))) return r;
+                current = res->placeholder_streams;
+            }
+            float v = 0.0f;
+            if ((r = rate(res->lanes, &v))) return r;
+            res->verified_pairs_per_s = v;
+            best_seen = std::max(best_seen, v);
+            if (v >= 0.975f * res->pairs_per_s) break;
+        }
+        if (res->attempts > DEMON_LANES_MAX_ATTEMPTS) res->attempts = DEMON_LANES_MAX_ATTEMPTS;
+    } else {
+        res->attempts = 1;
+    }
     return DEMON_OK;
 }
 

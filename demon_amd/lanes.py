@@ -121,6 +121,21 @@ class LaneGroup:
             except OSError:
                 pass
 
+    def _measure(self, k, n, iterations, bootstrap_only, steps_per_lane):
+        """pairs/s of steps_per_lane * k steps round robin over the first k lanes (resident inputs), best of two rounds"""
+        import time
+        best = 0.0
+        for _ in range(2):
+            self.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps_per_lane * k):
+                c = self.ctxs[i % k]
+                c.run_bootstrap(n) if bootstrap_only else c.run_full(n, iterations)
+            for c in self.ctxs[:k]:
+                c.synchronize()
+            best = max(best, n * steps_per_lane * k / (time.perf_counter() - t0))
+        return best
+
     def _keep(self, keep, placeholder_streams, rate):
         for c in self.ctxs[keep:]:
             c.close()
@@ -135,14 +150,14 @@ class LaneGroup:
             self._side_off = False
         self.mapping = {"lanes": keep, "placeholder_streams": placeholder_streams, "pairs_per_s": rate}
 
-    def calibrate(self, n, iterations=3, bootstrap_only=False, steps_per_lane=4, candidates=None, pads=(0, 1, 2, 3), reuse=False):
+    def calibrate(self, n, iterations=3, bootstrap_only=False, steps_per_lane=4, candidates=None, pads=(0, 1, 2, 3, 4, 5), reuse=False):
         """demon_lanes_calibrate (inputs must be resident in every lane): the rate of `steps_per_lane * k` steps on the first k lanes
         for k = 1 .. len(group), under the stream mapping behind 0 .. max(pads) placeholder streams (the mapping of HIP streams onto
         hardware queues depends on every stream alive in the process: the same lanes measured 3480 .. 4220 pairs/s over 0 .. 3
         placeholders, `gpurun_out/r5m/pad.txt`).  Keeps the best (placeholders, k) among the `candidates` lane counts (default:
         all), closes the lanes beyond k and returns {"k@placeholders": pairs/s}.  A group that keeps ONE lane turns it back into a
         plain context (side branches on, latency plan).  reuse: a winner remembered for this process environment (mapping_key())
-        is re-applied without measuring; returns {} then."""
+        is applied and measured once; when its rate is back ({} is returned) the sweep is skipped, else the full calibration runs."""
         from ._lib import LanesResult
         import ctypes
         ks = [k for k in sorted(set(candidates or range(1, len(self.ctxs) + 1))) if 1 <= k <= len(self.ctxs)]
@@ -152,26 +167,32 @@ class LaneGroup:
         if reuse:
             self._cache_load()
             hit = self._cache.get(key)
-            if hit and 1 <= hit["lanes"] <= len(self.ctxs):
-                self._keep(hit["lanes"], hit["placeholder_streams"], hit["pairs_per_s"])
+            if hit and hit["lanes"] in ks:
+                # apply the remembered winner and MEASURE it: the placeholder count alone does not reproduce a mapping (see above);
+                # only a rate within 2.5 % of the remembered one is taken, anything else falls through to the full calibration
                 self._apply(hit["placeholder_streams"])
-                self.mapping["reused"] = True
-                return {}
+                got = self._measure(hit["lanes"], n, iterations, bootstrap_only, steps_per_lane)
+                if got >= 0.975 * hit["pairs_per_s"]:
+                    self._keep(hit["lanes"], hit["placeholder_streams"], hit["pairs_per_s"])
+                    self.mapping.update(reused=True, verified_pairs_per_s=got, attempts=1)
+                    return {}
         res = LanesResult()
         arr, k = self._handles()
         first = self.ctxs[0]
+        mask = 0
+        for kk in ks:
+            mask |= 1 << kk
         first._check(first.lib.demon_lanes_calibrate(arr, k, int(n), int(iterations), int(bool(bootstrap_only)), int(steps_per_lane),
-                                                     int(max(pads) if len(self.ctxs) > 1 and pads else 0), ctypes.byref(res)))
-        rates, best = {}, None
+                                                     int(max(pads) if len(self.ctxs) > 1 and pads else 0), mask, ctypes.byref(res)))
+        rates = {}
         for i in range(res.ntable):
             e = res.table[i]
             rates["%d@%d" % (e.lanes, e.placeholder_streams)] = float(e.pairs_per_s)
-            if e.lanes in ks and (e.placeholder_streams in pads or e.placeholder_streams == 0) and (best is None or e.pairs_per_s > best[0]):
-                best = (float(e.pairs_per_s), e.lanes, e.placeholder_streams)
-        if best[2] != res.placeholder_streams:        # (the C side left the lanes on ITS winner; ours is restricted to `candidates`)
-            self._apply(best[2])
-        self._keep(best[1], best[2], best[0])
-        self._cache[key] = dict(self.mapping)
+        # (the C side left the lanes on its winner, applied again and measured again there: `verified`)
+        self._keep(res.lanes, res.placeholder_streams, float(res.pairs_per_s))
+        self.mapping["verified_pairs_per_s"] = float(res.verified_pairs_per_s)
+        self.mapping["attempts"] = int(res.attempts)
+        self._cache[key] = {k2: self.mapping[k2] for k2 in ("lanes", "placeholder_streams", "pairs_per_s")}
         self._cache_store()
         return rates
 

@@ -167,26 +167,32 @@ int demon_acquire_streams(demon_ctx *ctx);
  *   demon_lanes_calibrate : for 0 .. max_placeholders placeholder streams and k = 1 .. nctx lanes: the rate of steps_per_lane * k
  *                           forward passes (demon_run_full(n, iterations), or demon_run_bootstrap when bootstrap_only) fed round
  *                           robin to the first k contexts over their RESIDENT inputs (demon_upload_inputs first), best of two
- *                           rounds by the host clock.  Fills `result` (winner + the whole table), leaves the contexts on the
- *                           winning stream mapping; closing the contexts beyond result->lanes is the caller's business.  A winner
- *                           measured once can be re-applied in a later process of the same kind with demon_lanes_apply.
+ *                           rounds by the host clock.  lanes_mask: bit k set = k lanes may win (0: any).  Fills `result` (winner +
+ *                           the whole table) and leaves the contexts on the winning mapping, VERIFIED: the queue a new stream gets
+ *                           also depends on how many streams the process created before, so the winner is applied and measured
+ *                           again, with one throw-away stream more per attempt, until its rate is back (verified_pairs_per_s,
+ *                           attempts).  Closing the contexts beyond result->lanes is the caller's business.  A winner measured once
+ *                           can be tried in a later process of the same kind with demon_lanes_apply (measure it there too).
  * Contexts of a group: same device, side_branches off (demon_set_option) when nctx > 1, one host thread. */
 #define DEMON_LANES_MAX 8
 #define DEMON_LANES_MAX_PLACEHOLDERS 7
 #define DEMON_LANES_TABLE_CAP 64
+#define DEMON_LANES_MAX_ATTEMPTS 16
 typedef struct demon_lanes_entry {
     int lanes, placeholder_streams;
     float pairs_per_s;
 } demon_lanes_entry;
 typedef struct demon_lanes_result {
     int lanes, placeholder_streams;   /* the winner */
-    float pairs_per_s;
+    float pairs_per_s;                /* its rate in the sweep */
+    float verified_pairs_per_s;       /* its rate measured AGAIN in the state the contexts are left in */
+    int attempts;                     /* how often the winner had to be applied until that rate was within 2.5 % of the sweep's */
     int ntable;
     demon_lanes_entry table[DEMON_LANES_TABLE_CAP];
 } demon_lanes_result;
 int demon_lanes_apply(demon_ctx *const *ctxs, int nctx, int placeholder_streams);
 int demon_lanes_calibrate(demon_ctx *const *ctxs, int nctx, int n, int iterations, int bootstrap_only, int steps_per_lane,
-                          int max_placeholders, demon_lanes_result *result);
+                          int max_placeholders, unsigned lanes_mask, demon_lanes_result *result);
 int demon_download_outputs(demon_ctx *ctx, int n, const demon_outputs *out, float *predict_depth0);
 /* Pipelining across contexts (copy / compute overlap): the _async variants only enqueue on the context's stream; the host buffers
  * must be page-locked (demon_host_register pins an existing allocation, e.g. a numpy array) and stay untouched until

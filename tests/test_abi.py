@@ -183,8 +183,9 @@ def test_package_import_sets_the_hardware_queue_count():
     import sys
     code = "import os; import demon_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    for env_extra, want in (({}, "8"), ({"GPU_MAX_HW_QUEUES": "4"}, "4"), ({"DEMON_HW_QUEUES": "0"}, "None"), ({"DEMON_HW_QUEUES": "6"}, "6")):
-        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "DEMON_HW_QUEUES")}
+    for env_extra, want in (({}, "8"), ({"GPU_MAX_HW_QUEUES": "4"}, "4"), ({"DEMON_HW_QUEUES": "0"}, "None"), ({"DEMON_HW_QUEUES": "6"}, "6"),
+                            ({"LOCAL_RANK": "0"}, "16"), ({"LOCAL_RANK": "0", "DEMON_HW_QUEUES": "8"}, "8")):   # (16 under a torch.distributed launcher)
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "DEMON_HW_QUEUES", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
         env.update(env_extra)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and r.stdout.strip() == want, (env_extra, r.stdout, r.stderr[-500:])

@@ -51,7 +51,7 @@ def test_bench_under_torch_distributed_run_with_the_rccl_route():
     assert len(pr["ranks"]) == 1 and pr["ranks"][0]["rank"] == 0 and pr["lanes"] == [rec["config"]["lanes"]]
     assert pr["pairs_per_s_min"] == pr["pairs_per_s_max"] >= rec["value"] * (1 - 1e-6)           # the reported time is the MAX over ranks
     m = pr["ranks"][0]["lanes_mapping"]
-    assert m["lanes"] == rec["config"]["lanes"] and 0 <= m["placeholder_streams"] <= 3
+    assert m["lanes"] == rec["config"]["lanes"] and 0 <= m["placeholder_streams"] <= 5
     assert pr["ranks"][0]["lanes_calibration_pairs_per_s"] == rec["config"]["lanes_calibration_pairs_per_s"]
     assert rec["value_single_lane"] == rec["single_lane"]["pairs_per_s"] > 100
 
