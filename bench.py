@@ -296,8 +296,12 @@ def main():
             "lanes_calibration_pairs_per_s": {str(k): round(v, 1) for k, v in lane_rates.items()} if lane_rates else None}
     per_rank = [mine]
     if distributed:
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+        try:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            per_rank = gathered
+        except Exception as e:      # diagnostics must never cost the run its JSON line
+            mine["gather_error"] = repr(e)[:200]
     out1 = ctx.download_outputs(n, with_depth0=not boot_only)
     if args.lanes > 1 and shipped_plans:
         ctx.load_tuned_plan(n, lanes=plan_lanes)   # the per-launch profile below is of the kernels the headline ran
