@@ -217,6 +217,9 @@ typedef struct demon_launch_record {
     float ms;          /* whole step, including the split-K reduce launch where one follows */
     float reduce_ms;   /* of which: the conv_splitk_reduce launch (0 when the step has none) -- ms - reduce_ms is the kernel alone */
 } demon_launch_record;
+/* Under option "tune_lanes" > 1 every step is timed as that many CONCURRENT replays on as many streams, all writing the same output
+ * buffers and split-K workspace: valid for timing only -- the context's resident activations and outputs are garbage afterwards (run a
+ * pass again before downloading anything). */
 int demon_profile_full(demon_ctx *ctx, int n, int iterations, int repeats, demon_launch_record *records, int cap,
                        int *count);
 
