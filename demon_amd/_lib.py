@@ -68,6 +68,9 @@ SIGNATURES = {
     "demon_plan_clear": (_I, [_P, _I]),
     "demon_lanes_apply": (_I, [ctypes.POINTER(_P), _I, _I]),
     "demon_lanes_calibrate": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I, _I, _I, ctypes.c_uint, ctypes.POINTER(LanesResult)]),
+    "demon_set_cu_mask": (_I, [_P, ctypes.POINTER(ctypes.c_uint32), _I]),
+    "demon_lanes_run_group": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
+    "demon_hw_queues_hint": (_I, [_I]),
     "demon_autotune": (_I, [_P, _I]),
     "demon_num_layers": (_I, [_P]),
     "demon_plan_get": (_I, [_P, _I, _I, ctypes.c_char_p, _I, c_int_p, c_int_p, c_int_p]),

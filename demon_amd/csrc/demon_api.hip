@@ -153,6 +153,7 @@ struct Variable {
 }  // namespace
 
 struct demon_ctx {
+    unsigned long long serial = 0;   // unique per created context (keys of demon_lanes_run_group's graphs: an address can come back)
     int device = 0, max_batch = 0, H = 0, W = 0;
     int variant = 1;  // 1 = networks_original.py / blocks_original.py, 2 = v2/networks.py / v2/blocks.py
     hipStream_t stream = nullptr;
@@ -179,6 +180,11 @@ struct demon_ctx {
     std::vector<hipStream_t> tune_streams;   // throughput-mode autotune (option tune_lanes): concurrent replays need streams of their own
     std::vector<hipEvent_t> tune_events;
     int opt_tune_lanes = 1;
+    // demon_set_cu_mask: the context's streams are created with hipExtStreamCreateWithCUMask on this mask (bit i -> XCD i % 8, CU slot
+    // i / 8 of that XCD); empty = every CU (plain streams).  A lane group can give each lane a share of every XCD (demon_amd/lanes.py)
+    std::vector<uint32_t> cu_mask;
+    std::map<std::string, hipGraphExec_t> group_graphs;   // demon_lanes_run_group: one graph holding several lanes' passes as parallel branches (owned by lane 0)
+    std::vector<hipEvent_t> group_events;
     std::vector<hipStream_t> placeholder_streams;   // demon_lanes_apply / demon_lanes_calibrate: idle streams that shift the lanes' stream -> hardware-queue mapping (owned by lane 0)
     std::vector<hipEvent_t> events;  // fork / join events, one per use inside a sequence
     int opt_side_branches = 1;
@@ -1905,6 +1911,19 @@ void prepare_stream_weights(demon_ctx *c)
     for (auto &L : c->layers) refresh_stream_weights(L.get(), c->stream);
 }
 
+// a context's stream: on its CU mask when it has one (demon_set_cu_mask), else a plain non-blocking stream
+hipError_t make_stream(const demon_ctx *c, hipStream_t *st)
+{
+    if (!c->cu_mask.empty()) return hipExtStreamCreateWithCUMask(st, (uint32_t)c->cu_mask.size(), c->cu_mask.data());
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
+void drop_group_graphs(demon_ctx *c)
+{
+    for (auto &g : c->group_graphs) hipGraphExecDestroy(g.second);
+    c->group_graphs.clear();
+}
+
 // between demon_release_streams and demon_acquire_streams a context has no stream: nothing may fall onto the null stream
 const char *const kNoStream = "the context gave its HIP streams back (demon_release_streams); call demon_acquire_streams first";
 
@@ -1989,6 +2008,8 @@ static int create_impl(demon_ctx **out, int device, int max_batch, int height, i
     if (device < 0 || device >= ndev) return fail(nullptr, DEMON_ERR_INVALID, "device index out of range");
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, DEMON_ERR_HIP, "hipSetDevice failed");
     std::unique_ptr<demon_ctx> c(new demon_ctx);
+    static std::atomic<unsigned long long> next_serial{1};
+    c->serial = next_serial.fetch_add(1);
     c->device = device; c->max_batch = max_batch; c->H = height; c->W = width; c->variant = variant;
     c->guard_bytes = guard_bytes_from_env();   // poison harness: every allocation of this context between NaN canaries
     if (const char *fp = getenv("DEMON_FUSED_PAIRS")) c->opt_fused_pairs = atoi(fp) ? 1 : 0;
@@ -2090,6 +2111,8 @@ int demon_destroy(demon_ctx *c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
+    drop_group_graphs(c);
+    for (hipEvent_t e : c->group_events) hipEventDestroy(e);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     for (hipStream_t st : c->tune_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
     for (hipStream_t st : c->placeholder_streams) hipStreamDestroy(st);
@@ -2625,6 +2648,7 @@ int demon_release_streams(demon_ctx *c)
     // the next run call captures again on the new streams (a few milliseconds, set-up time like the exchange itself).
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);
     c->graphs.clear();
+    drop_group_graphs(c);
     // the throughput-mode tuner's streams take part in the stream -> hardware-queue mapping as well (re-created on demand)
     for (hipStream_t st : c->tune_streams) { hipStreamSynchronize(st); hipStreamDestroy(st); }
     c->tune_streams.clear();
@@ -2635,8 +2659,8 @@ int demon_acquire_streams(demon_ctx *c)
 {
     if (!c) return DEMON_ERR_INVALID;
     hipSetDevice(c->device);
-    if (!c->stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    if (!c->side_stream && c->variant != 0 && hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (!c->stream) HIP_TRY(c, make_stream(c, &c->stream));
+    if (!c->side_stream && c->variant != 0 && make_stream(c, &c->side_stream) != hipSuccess) {
         c->side_stream = nullptr;
         c->opt_side_branches = 0;
     }
@@ -2677,6 +2701,74 @@ int demon_lanes_apply(demon_ctx *const *ctxs, int nctx, int placeholder_streams)
     }
     for (int i = 0; i < nctx; ++i)
         if ((r = demon_acquire_streams(ctxs[i]))) return r == DEMON_ERR_HIP ? fail(c0, r, "lane " + std::to_string(i) + ": " + ctxs[i]->err) : r;
+    return DEMON_OK;
+}
+
+
+int demon_hw_queues_hint(int under_launcher) { return under_launcher ? 16 : 8; }
+
+// ---- CU masks: a context's streams restricted to a subset of the compute units (hipExtStreamCreateWithCUMask).  Bit i of the mask
+// is CU slot i / 8 of XCD i % 8 (the driver deals mask bits round robin to the XCDs); a mask must leave every XCD some CUs.  The
+// streams are exchanged at once (nothing may be in flight); nwords = 0 removes the mask.  Cached graphs are dropped.
+int demon_set_cu_mask(demon_ctx *c, const uint32_t *mask, int nwords)
+{
+    if (!c || nwords < 0 || nwords > 16 || (nwords && !mask)) return DEMON_ERR_INVALID;
+    if (nwords) {
+        // every XCD keeps at least one CU: a queue without CUs on an XCD that is still dealt workgroups would never finish
+        unsigned per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 32 * nwords; ++i) per_xcd[i & 7] += (mask[i >> 5] >> (i & 31)) & 1u;
+        for (int x = 0; x < 8; ++x)
+            if (!per_xcd[x]) return fail(c, DEMON_ERR_INVALID, "CU mask leaves XCD " + std::to_string(x) + " without compute units");
+    }
+    const bool had = c->stream != nullptr;
+    int r = demon_release_streams(c);
+    if (r) return r;
+    c->cu_mask.assign(mask, mask + nwords);
+    return had ? demon_acquire_streams(c) : DEMON_OK;
+}
+
+// ---- one hipGraph for a GROUP of lanes: the passes of ctxs[0 .. nctx) as parallel branches of a single graph, launched on lane 0's
+// stream (one hipGraphLaunch = nctx steps; the lanes join at the end of the graph).  The alternative to feeding the lanes' own graphs
+// round robin (demon_run_full on each): no stream -> hardware-queue calibration of ours, the runtime places the branches itself.
+int demon_lanes_run_group(demon_ctx *const *ctxs, int nctx, int n, int iterations, int bootstrap_only)
+{
+    int r = lanes_check(ctxs, nctx);
+    if (r) return r;
+    demon_ctx *c0 = ctxs[0];
+    if (iterations < 0 || iterations > 64) return fail(c0, DEMON_ERR_INVALID, "iterations out of range");
+    for (int i = 0; i < nctx; ++i)
+        if ((r = check_batch(ctxs[i], n))) return i ? fail(c0, r, "lane " + std::to_string(i) + ": " + ctxs[i]->err) : r;
+    hipSetDevice(c0->device);
+    std::string key = std::to_string(bootstrap_only ? 1 : 0) + ":" + std::to_string(n) + ":" + std::to_string(iterations);
+    for (int i = 0; i < nctx; ++i) key += ":" + std::to_string(ctxs[i]->serial) + "." + std::to_string(ctxs[i]->opt_side_branches);
+    auto it = c0->group_graphs.find(key);
+    if (it == c0->group_graphs.end()) {
+        while ((int)c0->group_events.size() < nctx) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(c0, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c0->group_events.push_back(e);
+        }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        for (int i = 0; i < nctx; ++i) ctxs[i]->err.clear();
+        HIP_TRY(c0, hipStreamBeginCapture(c0->stream, hipStreamCaptureModeThreadLocal));
+        bool ok = hipEventRecord(c0->group_events[0], c0->stream) == hipSuccess;
+        for (int i = 1; ok && i < nctx; ++i) ok = hipStreamWaitEvent(ctxs[i]->stream, c0->group_events[0], 0) == hipSuccess;   // the lanes' streams join the capture
+        for (int i = 0; ok && i < nctx; ++i) enqueue_sequence(ctxs[i], bootstrap_only ? SEQ_BOOT : SEQ_FULL, n, bootstrap_only ? 0 : iterations, ctxs[i]->stream);
+        for (int i = 1; ok && i < nctx; ++i)
+            ok = hipEventRecord(c0->group_events[i], ctxs[i]->stream) == hipSuccess && hipStreamWaitEvent(c0->stream, c0->group_events[i], 0) == hipSuccess;
+        const hipError_t ec = hipStreamEndCapture(c0->stream, &graph);
+        for (int i = 0; i < nctx; ++i)
+            if (!ctxs[i]->err.empty()) { if (i) c0->err = ctxs[i]->err; ok = false; }
+        if (!ok || ec != hipSuccess) {
+            if (graph) hipGraphDestroy(graph);
+            return fail(c0, DEMON_ERR_HIP, c0->err.empty() ? std::string("capture of the lane group failed: ") + hipGetErrorString(ec) : c0->err);
+        }
+        HIP_TRY(c0, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        it = c0->group_graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(c0, hipGraphLaunch(it->second, c0->stream));
     return DEMON_OK;
 }
 
@@ -2746,7 +2838,7 @@ int demon_lanes_calibrate(demon_ctx *const *ctxs, int nctx, int n, int iteration
     // that was measured.
     res->verified_pairs_per_s = res->pairs_per_s;
     if (nctx > 1) {
-        float best_seen = -1.0f;
+        bool reproduced = false;
         for (res->attempts = 1; res->attempts <= DEMON_LANES_MAX_ATTEMPTS; ++res->attempts) {
             if (res->attempts > 1 || res->placeholder_streams != current) {
                 if (res->attempts > 1) {
@@ -2759,10 +2851,11 @@ int demon_lanes_calibrate(demon_ctx *const *ctxs, int nctx, int n, int iteration
             float v = 0.0f;
             if ((r = rate(res->lanes, &v))) return r;
             res->verified_pairs_per_s = v;
-            best_seen = std::max(best_seen, v);
-            if (v >= 0.975f * res->pairs_per_s) break;
+            if (v >= 0.975f * res->pairs_per_s) { reproduced = true; break; }
         }
-        if (res->attempts > DEMON_LANES_MAX_ATTEMPTS) res->attempts = DEMON_LANES_MAX_ATTEMPTS;
+        // every attempt missed the bar: the lanes stay on the LAST mapping tried, `verified_pairs_per_s` is its measured rate, and
+        // attempts = DEMON_LANES_MAX_ATTEMPTS + 1 says that the sweep's winner was never reproduced (callers must not cache it)
+        if (!reproduced) res->attempts = DEMON_LANES_MAX_ATTEMPTS + 1;
     } else {
         res->attempts = 1;
     }
@@ -3074,6 +3167,7 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
     hipSetDevice(c->device);
     if (!out || !in || !w || !bias || n < 1 || cin < 1 || cout < 1 || h < 1 || wd < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1)
         return fail(c, DEMON_ERR_INVALID, "bad argument");
+    if (!c->stream) return fail(c, DEMON_ERR_NOT_READY, kNoStream);   // (never the null stream: include/demon_hip.h, demon_release_streams)
     demon_ctx scratch;  // owns the temporary device allocations of this call
     scratch.device = c->device;
     scratch.max_batch = n;
@@ -3093,7 +3187,8 @@ static int run_single_layer(demon_ctx *c, Layer::Kind kind, float *out, const fl
     L.in = buffer(&scratch, "in", cin, h, wd);
     L.out = buffer(&scratch, "out", cout, ho, wo);
     int rc = DEMON_OK;
-    if (!L.in.base || !L.out.base || !plan_layer(&scratch, &L)) rc = fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    if (!L.in.base || !L.out.base || !plan_layer(&scratch, &L))   // (buffer() says why when it refused a size: 2^31-element limit)
+        rc = fail(c, DEMON_ERR_HIP, scratch.err.empty() ? std::string("temporary device allocation failed") : scratch.err);
     if (!rc && upload_kernel(&scratch, &L, w)) rc = fail(c, DEMON_ERR_HIP, scratch.err);
     if (!rc && hipMemcpy(L.d_bias, bias, sizeof(float) * cout, hipMemcpyHostToDevice) != hipSuccess) rc = fail(c, DEMON_ERR_HIP, "bias upload failed");
     if (!rc && hipMemcpy(L.in.base, in, sizeof(float) * (size_t)n * cin * h * wd, hipMemcpyHostToDevice) != hipSuccess)
@@ -3154,7 +3249,8 @@ int demon_bench_layer(demon_ctx *c, int kind, int n, int cin, int h, int wd, int
     L.in = buffer(&scratch, "in", cin, h, wd);
     L.out = buffer(&scratch, "out", cout, ho, wo);
     int rc = DEMON_OK;
-    if (!L.in.base || !L.out.base || !plan_layer(&scratch, &L)) rc = fail(c, DEMON_ERR_HIP, "temporary device allocation failed");
+    if (!L.in.base || !L.out.base || !plan_layer(&scratch, &L))   // (buffer() says why when it refused a size: 2^31-element limit)
+        rc = fail(c, DEMON_ERR_HIP, scratch.err.empty() ? std::string("temporary device allocation failed") : scratch.err);
     if (!rc) {
         // deterministic pseudo-random fill (full-range values: zero-filled operands would clock higher)
         const size_t nin = (size_t)n * cin * h * wd, nw = (size_t)L.ncls * L.Krows * L.Mpad;

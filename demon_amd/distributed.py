@@ -14,6 +14,94 @@ import ctypes
 import numpy as np
 
 
+# ---- host placement: a rank's host threads and pinned buffers next to ITS GPU ------------------------------------------------------------
+# One process per GPU on an 8-GPU node: every rank feeds ~240-launch graphs (4 lanes) and, host to host, copies 39 MB in / 10 MB out per
+# step through page-locked buffers.  The GPU hangs off one NUMA node; a rank whose thread (and whose pinned pages, first touched by that
+# thread) lives on the other socket pays a cross-socket hop on every doorbell and every DMA (SURVEY.md section 8e "watch").  The node
+# comes from sysfs -- /sys/class/drm/card*/device/numa_node of the PCI device the HIP runtime names for the ordinal -- and the binding is
+# plain sched_setaffinity on that node's cpulist (memory then follows first touch; no libnuma in the image).  Everything degrades to a
+# no-op with a reason: no sysfs entry, node -1 (single-socket or virtualised box), an affinity mask that excludes the node.
+def gpu_pci_bus_id(device):
+    """'0000:c1:00.0' of HIP device `device` (torch if it is loaded, else rocm-smi-free sysfs order), or None"""
+    import sys
+    torch = sys.modules.get("torch")
+    try:
+        if torch is not None and torch.cuda.is_available():
+            p = torch.cuda.get_device_properties(device)
+            if hasattr(p, "pci_bus_id"):
+                return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        pass
+    return None
+
+
+def gpu_numa_node(device, sysfs="/sys"):
+    """(numa node, how it was found) of HIP device `device`; node None when unknown"""
+    import glob
+    import os
+    bus = gpu_pci_bus_id(device)
+    if bus:
+        path = os.path.join(sysfs, "bus/pci/devices", bus, "numa_node")
+        try:
+            with open(path) as f:
+                return int(f.read().strip()), path
+        except (OSError, ValueError):
+            pass
+    # fallback: the device-th AMD render node in sysfs order (vendor 0x1002), which is the order the runtime enumerates on one node
+    cards = []
+    for d in sorted(glob.glob(os.path.join(sysfs, "class/drm/renderD*/device"))):
+        try:
+            with open(os.path.join(d, "vendor")) as f:
+                if f.read().strip() != "0x1002":
+                    continue
+            with open(os.path.join(d, "numa_node")) as f:
+                cards.append((int(f.read().strip()), os.path.join(d, "numa_node")))
+        except (OSError, ValueError):
+            continue
+    if 0 <= device < len(cards):
+        return cards[device]
+    return None, "no sysfs entry for device %d" % device
+
+
+def parse_cpulist(text):
+    """'0-63,128-191' -> sorted list of ints"""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def bind_to_gpu_numa_node(device, sysfs="/sys", apply=True):
+    """Restricts this process to the CPUs of the NUMA node HIP device `device` is attached to (sched_setaffinity; memory follows
+    first touch, so call it BEFORE allocating / pinning host buffers).  Returns a record for the bench line:
+    {"numa_node", "cpus": count, "bound": bool, "why"}.  Never raises."""
+    import os
+    rec = {"numa_node": None, "cpus": None, "bound": False, "why": ""}
+    try:
+        node, how = gpu_numa_node(device, sysfs)
+        rec["numa_node"] = node
+        if node is None or node < 0:
+            rec["why"] = "no NUMA node for the GPU (%s)" % how
+            return rec
+        with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)) as f:
+            cpus = parse_cpulist(f.read())
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        rec["cpus"] = len(allowed)
+        if not allowed:
+            rec["why"] = "the process's affinity mask has no CPU of node %d" % node
+            return rec
+        if apply:
+            os.sched_setaffinity(0, allowed)
+        rec["bound"] = bool(apply)
+        rec["why"] = "node %d from %s" % (node, how)
+    except Exception as e:
+        rec["why"] = "binding failed: %r" % (e,)
+    return rec
+
+
 def shard_range(global_batch, rank, world):
     """rank r of `world` owns pairs [lo, hi); remainder pairs go to the lowest ranks."""
     base, rem = divmod(global_batch, world)

@@ -23,6 +23,7 @@ def _f32(a, shape=None, name="array"):
 
 
 class DemonContext:
+    created_in_process = 0     # contexts ever created here: the HIP runtime is initialised once this is > 0 (demon_amd.lanes)
     OUTPUT_KEYS = ("predict_flow5", "predict_conf5", "predict_flow2", "predict_conf2", "predict_depth2",
                    "predict_normal2", "predict_rotation", "predict_translation", "predict_scale")
 
@@ -37,6 +38,7 @@ class DemonContext:
         rc = create(ctypes.byref(self.h), device, max_batch, height, width)
         if rc != 0:
             raise DemonError("demon_create failed (%d): %s" % (rc, self.lib.demon_last_error(None).decode()))
+        DemonContext.created_in_process += 1
         self.device, self.max_batch, self.H, self.W = device, max_batch, height, width
         self.h2, self.w2, self.h5, self.w5 = height // 4, width // 4, height // 32, width // 32
 
@@ -50,6 +52,7 @@ class DemonContext:
         rc = self.lib.demon_create_ops(ctypes.byref(self.h), device)
         if rc != 0:
             raise DemonError("demon_create_ops failed (%d): %s" % (rc, self.lib.demon_last_error(None).decode()))
+        DemonContext.created_in_process += 1
         self.device, self.max_batch, self.H, self.W = device, 0, 0, 0
         self.h2 = self.w2 = self.h5 = self.w5 = 0
         return self

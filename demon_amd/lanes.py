@@ -24,7 +24,76 @@ JSON file, across processes: `calibrate(reuse=True)` then re-applies it with `de
 Weights exist once per lane (device-to-device copy of the packed slab: demon_copy_weights_from); nothing is shared at run time,
 so lanes need no locking: a lane is used by one host thread at a time.
 """
+import os
+import sys
+import warnings
+
 from .engine import DemonContext
+
+# ---- hardware queues ------------------------------------------------------------------------------------------------------------
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two busy lanes that share
+# one serialise.  Measured on an MI355X at batch 32 (round 5, one box per file):
+#   plain process (gpurun_out/r5c/ab.txt):  4 queues -> best 3 lanes, 4 488 - 4 499 pairs/s;  8 queues -> best 4 lanes, 4 622 - 4 640 (+3 %);
+#                                           5 / 6 / 10 / 12 / 16 queues and 5 - 6 lanes: no gain
+#   under torch.distributed.run with the RCCL communicator alive (gpurun_out/r5h_torchrun_queues.txt): 8 queues -> 3 lanes, 4 452;
+#                                           16 queues -> 4 lanes, 4 646
+# The runtime reads the variable ONCE, when it initialises (first HIP call of the process).  Until round 5 `import demon_amd` set it for
+# everybody; now only this module does, when it is imported -- a process that never runs lanes keeps the runtime's default, and a
+# process that imports this module too late (a context or torch.cuda already exists) is TOLD that the request had no effect.
+# DEMON_HW_QUEUES=<n> picks another count, DEMON_HW_QUEUES=0 leaves the environment alone; a value the caller exported wins.  A C / C++
+# host does the same with demon_hw_queues_hint() (INTEGRATION.md section 6).
+HW_QUEUES = {"requested": None, "env": os.environ.get("GPU_MAX_HW_QUEUES"), "set_by": "caller" if "GPU_MAX_HW_QUEUES" in os.environ else None,
+             "runtime_was_up": False}
+
+
+def _hip_runtime_is_up():
+    if DemonContext.created_in_process:
+        return True
+    torch = sys.modules.get("torch")
+    try:
+        return bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+def request_hw_queues():
+    """exports GPU_MAX_HW_QUEUES (8, or 16 under a torch.distributed launcher) unless the caller already chose; records what happened
+    in HW_QUEUES (every LaneGroup / bench record carries it)"""
+    q = os.environ.get("DEMON_HW_QUEUES") or ("16" if ("LOCAL_RANK" in os.environ or "TORCHELASTIC_RUN_ID" in os.environ) else "8")
+    HW_QUEUES["requested"] = q
+    if q == "0" or "GPU_MAX_HW_QUEUES" in os.environ:
+        return HW_QUEUES
+    HW_QUEUES["runtime_was_up"] = _hip_runtime_is_up()
+    os.environ["GPU_MAX_HW_QUEUES"] = q
+    HW_QUEUES["env"], HW_QUEUES["set_by"] = q, "demon_amd.lanes"
+    if HW_QUEUES["runtime_was_up"]:
+        warnings.warn("demon_amd.lanes: GPU_MAX_HW_QUEUES=%s was exported AFTER the HIP runtime initialised -- it has no effect in this "
+                      "process (import demon_amd.lanes, or export the variable, before the first context / torch.cuda call)" % q, RuntimeWarning)
+    return HW_QUEUES
+
+
+request_hw_queues()
+
+
+def cu_masks(lanes, layout="block", share=1, slots=32, xcds=8):
+    """CU masks (lists of 32-bit words) that split the chip between `lanes` lanes, every lane with the same share of EVERY XCD (a mask
+    bit i is CU slot i // 8 of XCD i % 8; a slot k is CU k // 4 of shader engine k % 4).  layout "block": lane j owns the slots
+    [j * slots / lanes, (j + 1) * slots / lanes) -- two CUs of every shader engine for four lanes; "stride": the slots k with
+    k % lanes == j -- one whole shader engine per XCD for four lanes.  share > 1: a lane also gets the slots of the next share - 1
+    lanes (overlapping partitions)."""
+    per = slots // lanes
+    out = []
+    for j in range(lanes):
+        own = set()
+        for d in range(share):
+            jj = (j + d) % lanes
+            own |= {k for k in range(slots) if (k // per == jj if layout == "block" else k % lanes == jj)}
+        bits = 0
+        for k in own:
+            for x in range(xcds):
+                bits |= 1 << (k * xcds + x)
+        out.append([(bits >> (32 * w)) & 0xffffffff for w in range(slots * xcds // 32)])
+    return out
 
 
 class LaneGroup:
@@ -112,12 +181,25 @@ class LaneGroup:
 
     @classmethod
     def _cache_store(cls):
+        """merges this process's winners into the file (other ranks write other keys: re-read just before writing) and replaces it
+        atomically, so a concurrent reader never sees a truncated file"""
         import json
+        import tempfile
         path = cls._cache_file()
         if path:
             try:
-                with open(path, "w") as f:
-                    json.dump(cls._cache, f, indent=1, sort_keys=True)
+                merged = {}
+                if os.path.isfile(path):
+                    try:
+                        with open(path) as f:
+                            merged = json.load(f)
+                    except (OSError, ValueError):
+                        merged = {}
+                merged.update(cls._cache)
+                fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + ".", suffix=".tmp", dir=os.path.dirname(os.path.abspath(path)))
+                with os.fdopen(fd, "w") as f:
+                    json.dump(merged, f, indent=1, sort_keys=True)
+                os.replace(tmp, path)
             except OSError:
                 pass
 
@@ -148,7 +230,7 @@ class LaneGroup:
             if self._owns_first:
                 self.ctxs[0].load_tuned_plan(self._plan_batch, lanes=1)
             self._side_off = False
-        self.mapping = {"lanes": keep, "placeholder_streams": placeholder_streams, "pairs_per_s": rate}
+        self.mapping = {"lanes": keep, "placeholder_streams": placeholder_streams, "pairs_per_s": rate, "hw_queues": dict(HW_QUEUES)}
 
     def calibrate(self, n, iterations=3, bootstrap_only=False, steps_per_lane=4, candidates=None, pads=(0, 1, 2, 3, 4, 5), reuse=False):
         """demon_lanes_calibrate (inputs must be resident in every lane): the rate of `steps_per_lane * k` steps on the first k lanes
@@ -192,8 +274,11 @@ class LaneGroup:
         self._keep(res.lanes, res.placeholder_streams, float(res.pairs_per_s))
         self.mapping["verified_pairs_per_s"] = float(res.verified_pairs_per_s)
         self.mapping["attempts"] = int(res.attempts)
-        self._cache[key] = {k2: self.mapping[k2] for k2 in ("lanes", "placeholder_streams", "pairs_per_s")}
-        self._cache_store()
+        # a winner whose rate never came back when it was applied again (attempts = DEMON_LANES_MAX_ATTEMPTS + 1) is not worth remembering
+        self.mapping["reproduced"] = bool(res.verified_pairs_per_s >= 0.975 * res.pairs_per_s)
+        if self.mapping["reproduced"] or res.lanes == 1:
+            self._cache[key] = {k2: self.mapping[k2] for k2 in ("lanes", "placeholder_streams", "pairs_per_s")}
+            self._cache_store()
         return rates
 
     def next_lane(self):
@@ -208,6 +293,22 @@ class LaneGroup:
     def upload_inputs(self, batches):
         """batches: one (image_pair, image2_2) per lane; they stay resident in the lanes' input buffers"""
         return [c.upload_inputs(*b) for c, b in zip(self.ctxs, batches)]
+
+    def set_cu_masks(self, masks):
+        """demon_set_cu_mask on every lane (masks: one list of 32-bit words per lane, cu_masks(); None / []: every CU again).  Lanes
+        on disjoint masks do not compete for compute units wherever the runtime puts their streams."""
+        import ctypes
+        for c, m in zip(self.ctxs, masks or [[]] * len(self.ctxs)):
+            arr = (ctypes.c_uint32 * max(1, len(m)))(*m)
+            c._check(c.lib.demon_set_cu_mask(c.h, arr, len(m)))
+
+    def run_group(self, n, launches, iterations=3, bootstrap_only=False):
+        """demon_lanes_run_group: `launches` launches of ONE graph that holds a pass of every lane as parallel branches (len(self)
+        steps per launch); returns without synchronising (synchronize() on lane 0 waits for all of them)"""
+        arr, k = self._handles()
+        first = self.ctxs[0]
+        for _ in range(launches):
+            first._check(first.lib.demon_lanes_run_group(arr, k, int(n), int(iterations), int(bool(bootstrap_only))))
 
     def run_resident(self, n, steps, iterations=3, bootstrap_only=False):
         """`steps` forward passes over the lanes' resident inputs, round robin; returns without synchronising"""

@@ -193,6 +193,21 @@ typedef struct demon_lanes_result {
 int demon_lanes_apply(demon_ctx *const *ctxs, int nctx, int placeholder_streams);
 int demon_lanes_calibrate(demon_ctx *const *ctxs, int nctx, int n, int iterations, int bootstrap_only, int steps_per_lane,
                           int max_placeholders, unsigned lanes_mask, demon_lanes_result *result);
+/* Two ways of running a lane group WITHOUT depending on where the runtime puts a stream (round 6; measured against the calibrated
+ * round-robin form):
+ *   demon_set_cu_mask     : the context's streams are re-created on a compute-unit mask (hipExtStreamCreateWithCUMask; nwords 32-bit
+ *                           words, bit i = CU slot i / 8 of XCD i % 8; nwords = 0: every CU again).  Nothing may be in flight; cached
+ *                           graphs are dropped.  A mask must leave every XCD at least one CU (DEMON_ERR_INVALID otherwise).  Lanes on
+ *                           disjoint masks do not compete for compute units, whatever hardware queue their streams share.
+ *   demon_lanes_run_group : ONE hipGraph holding the forward passes of ctxs[0 .. nctx) (demon_run_full(n, iterations), or
+ *                           demon_run_bootstrap when bootstrap_only) as parallel branches, launched on ctxs[0]'s stream: one call =
+ *                           nctx steps, enqueued without synchronising; demon_synchronize(ctxs[0]) waits for all of them.
+ *   demon_hw_queues_hint  : the GPU_MAX_HW_QUEUES value the lanes were measured best with (8 in a plain process, 16 when a
+ *                           torch.distributed / RCCL launcher's streams exist first); a host exports it BEFORE its first HIP call
+ *                           (the runtime reads it once, at initialisation) -- the library never changes the process environment. */
+int demon_set_cu_mask(demon_ctx *ctx, const uint32_t *mask, int nwords);
+int demon_lanes_run_group(demon_ctx *const *ctxs, int nctx, int n, int iterations, int bootstrap_only);
+int demon_hw_queues_hint(int under_launcher);
 int demon_download_outputs(demon_ctx *ctx, int n, const demon_outputs *out, float *predict_depth0);
 /* Pipelining across contexts (copy / compute overlap): the _async variants only enqueue on the context's stream; the host buffers
  * must be page-locked (demon_host_register pins an existing allocation, e.g. a numpy array) and stay untouched until

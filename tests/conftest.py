@@ -8,6 +8,10 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the lane tests run in this process: demon_amd.lanes exports GPU_MAX_HW_QUEUES when it is imported, which must happen before the
+# first HIP call (bench.py imports it at its top for the same reason)
+import demon_amd.lanes  # noqa: E402,F401
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -177,15 +177,29 @@ def test_pmc_family_covers_every_contraction_kernel():
 
 
 
-def test_package_import_sets_the_hardware_queue_count():
-    """demon_amd/__init__.py: GPU_MAX_HW_QUEUES=8 unless the caller chose a value or opted out (the HIP runtime reads it at its first call)"""
+def test_hardware_queue_request_is_made_by_the_lanes_module_only():
+    """`import demon_amd` leaves the process environment alone; `import demon_amd.lanes` exports GPU_MAX_HW_QUEUES = 8 (16
+    under a torch.distributed launcher) unless the caller chose a value or opted out, records what it did, and warns when a context
+    already exists (the HIP runtime reads the variable once, at its first call); the C ABI offers the same numbers as a hint"""
     import subprocess
     import sys
-    code = "import os; import demon_amd; print(os.environ.get('GPU_MAX_HW_QUEUES'))"
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    for env_extra, want in (({}, "8"), ({"GPU_MAX_HW_QUEUES": "4"}, "4"), ({"DEMON_HW_QUEUES": "0"}, "None"), ({"DEMON_HW_QUEUES": "6"}, "6"),
-                            ({"LOCAL_RANK": "0"}, "16"), ({"LOCAL_RANK": "0", "DEMON_HW_QUEUES": "8"}, "8")):   # (16 under a torch.distributed launcher)
+    code = ("import os; import demon_amd; a = os.environ.get('GPU_MAX_HW_QUEUES'); import demon_amd.lanes as L; "
+            "print(a, os.environ.get('GPU_MAX_HW_QUEUES'), L.HW_QUEUES['set_by'], L.HW_QUEUES['runtime_was_up'])")
+    for env_extra, want in (({}, "None 8 demon_amd.lanes False"), ({"GPU_MAX_HW_QUEUES": "4"}, "4 4 caller False"), ({"DEMON_HW_QUEUES": "0"}, "None None None False"),
+                            ({"DEMON_HW_QUEUES": "6"}, "None 6 demon_amd.lanes False"), ({"LOCAL_RANK": "0"}, "None 16 demon_amd.lanes False"),
+                            ({"LOCAL_RANK": "0", "DEMON_HW_QUEUES": "8"}, "None 8 demon_amd.lanes False")):
         env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "DEMON_HW_QUEUES", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
         env.update(env_extra)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0 and r.stdout.strip() == want, (env_extra, r.stdout, r.stderr[-500:])
+    # too late: a context was created before the module was imported -> the request is recorded as ineffective, with a warning
+    late = ("import warnings; from demon_amd import DemonContext; DemonContext.created_in_process = 1\n"
+            "with warnings.catch_warnings(record=True) as w:\n    warnings.simplefilter('always'); import demon_amd.lanes as L\n"
+            "print(L.HW_QUEUES['runtime_was_up'], len(w), 'no effect' in str(w[0].message))")
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "DEMON_HW_QUEUES", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run([sys.executable, "-c", late.replace("\\n", "\n")], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "True 1 True", (r.stdout, r.stderr[-800:])
+    from demon_amd import _lib
+    lib = _lib.load()
+    assert lib.demon_hw_queues_hint(0) == 8 and lib.demon_hw_queues_hint(1) == 16

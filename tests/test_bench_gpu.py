@@ -86,3 +86,34 @@ def test_bench_default_line_has_roofline_and_host_to_host_rates():
     assert p["pinned"] is True and p["outputs_equal_resident_run"] is True and 2 <= p["contexts"] <= 5
     assert p["pairs_per_s"] > x["end_to_end_pairs_per_s"]                                  # overlap beats synchronous pageable copies
     assert 0.5 < p["frac_of_resident"] < 1.5      # (two batches in flight hide per-launch latencies: the pipelined rate may exceed the one-stream rate)
+
+
+def test_headline_protocol_parity_under_torch_distributed_run():
+    """tools/lane_parity.py as a rank of the driver's launch (process group on nccl = RCCL first, so its streams shift the stream ->
+    hardware-queue mapping, and the package asks for 16 hardware queues): every pair of every kept lane against the CPU oracle"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29573", os.path.join("tools", "lane_parity.py"), "--lanes", "5", "--dist"]
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    rec = _json_lines(r.stdout)[-1]
+    assert rec["dist"] is True and rec["hw_queues"]["requested"] == "16" and rec["hw_queues"]["runtime_was_up"] is False
+    assert 1 <= rec["lanes_kept"] <= 5 and rec["mapping"]["verified_pairs_per_s"] > 0
+    assert rec["outputs_finite"] and rec["second_round_bit_equal"]
+    assert rec["pairs_checked"] == 32 * rec["lanes_kept"] and rec["worst_rel_l1"] < 1e-3, rec["worst_at"]
+
+
+def test_two_processes_calibrate_their_lanes_concurrently_on_one_gpu():
+    """the closest reachable stand-in for eight ranks calibrating at once: two processes on this one GPU, each running the whole
+    LaneGroup.calibrate sweep at the same time (batch 8 so that both fit comfortably); both must finish, verify their winner and
+    report it, and both must still compute finite, stable outputs"""
+    cmd = [sys.executable, os.path.join("tools", "lane_parity.py"), "--lanes", "4", "--batch", "8", "--no-oracle"]
+    procs = [subprocess.Popen(cmd, cwd=ROOT, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=1500) for p in procs]
+    recs = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-2000:], se[-3000:])
+        recs.append(_json_lines(so)[-1])
+    assert recs[0]["pid"] != recs[1]["pid"]
+    for rec in recs:
+        assert 1 <= rec["lanes_kept"] <= 4 and rec["mapping"]["verified_pairs_per_s"] > 0 and rec["mapping"]["attempts"] >= 1
+        assert rec["calibration_cells"] >= 4 and rec["outputs_finite"] and rec["second_round_bit_equal"]

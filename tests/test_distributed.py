@@ -258,3 +258,65 @@ def test_comm_count_reports_the_rccl_world():
         assert comm.count() == 1
     finally:
         comm.close()
+
+
+def test_numa_binding_from_a_sysfs_tree(tmp_path):
+    """demon_amd.distributed.bind_to_gpu_numa_node on a fabricated sysfs: the GPU's node -> that node's cpulist intersected with the
+    process's affinity mask; every failure mode degrades to a record with a reason (never raises, never binds)."""
+    import os
+    from demon_amd import distributed as D
+    assert D.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    mine = sorted(os.sched_getaffinity(0))
+    for i, (vendor, node) in enumerate((("0x1002", 1), ("0x10de", 0), ("0x1002", 0))):
+        d = tmp_path / "class" / "drm" / ("renderD%d" % (128 + i)) / "device"
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n")
+        (d / "numa_node").write_text("%d\n" % node)
+    for node, cpus in ((0, "%d" % mine[0]), (1, "%d-%d" % (mine[-1], mine[-1]))):
+        nd = tmp_path / "devices" / "system" / "node" / ("node%d" % node)
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cpus + "\n")
+    sysfs = str(tmp_path)
+    # device 0 = the first AMD render node (node 1), device 1 = the second AMD one (node 0): the foreign card is skipped
+    assert D.gpu_numa_node(0, sysfs)[0] == 1 and D.gpu_numa_node(1, sysfs)[0] == 0
+    rec = D.bind_to_gpu_numa_node(0, sysfs, apply=False)
+    assert rec["numa_node"] == 1 and rec["cpus"] == 1 and rec["bound"] is False and "node 1" in rec["why"]
+    before = os.sched_getaffinity(0)
+    try:
+        rec = D.bind_to_gpu_numa_node(1, sysfs, apply=True)
+        assert rec["bound"] is True and os.sched_getaffinity(0) == {mine[0]}
+    finally:
+        os.sched_setaffinity(0, before)
+    rec = D.bind_to_gpu_numa_node(7, sysfs)                       # no such device
+    assert rec["bound"] is False and rec["numa_node"] is None and rec["why"]
+    (tmp_path / "class" / "drm" / "renderD128" / "device" / "numa_node").write_text("-1\n")
+    rec = D.bind_to_gpu_numa_node(0, sysfs)                       # single-socket / virtualised: node -1
+    assert rec["bound"] is False and rec["numa_node"] == -1
+    assert os.sched_getaffinity(0) == before
+
+
+def test_lane_cache_file_is_merged_and_replaced_atomically(tmp_path, monkeypatch):
+    """ranks write different keys to one $DEMON_LANES_CACHE; a store must keep the other ranks' entries"""
+    import json
+    from demon_amd.lanes import LaneGroup
+    path = tmp_path / "lanes.json"
+    path.write_text(json.dumps({"dev1_x": {"lanes": 3, "placeholder_streams": 1, "pairs_per_s": 4000.0}}))
+    monkeypatch.setenv("DEMON_LANES_CACHE", str(path))
+    monkeypatch.setattr(LaneGroup, "_cache", {"dev0_x": {"lanes": 4, "placeholder_streams": 2, "pairs_per_s": 4700.0}})
+    LaneGroup._cache_store()
+    got = json.loads(path.read_text())
+    assert set(got) == {"dev0_x", "dev1_x"} and got["dev1_x"]["lanes"] == 3 and got["dev0_x"]["lanes"] == 4
+    assert [p.name for p in tmp_path.iterdir()] == ["lanes.json"]          # no temporary file left behind
+
+
+def test_cu_masks_partition_every_xcd():
+    from demon_amd.lanes import cu_masks
+    for layout in ("block", "stride"):
+        masks = cu_masks(4, layout)
+        bits = [sum(w << (32 * i) for i, w in enumerate(m)) for m in masks]
+        assert all(bin(b).count("1") == 64 for b in bits)
+        assert bits[0] | bits[1] | bits[2] | bits[3] == (1 << 256) - 1 and sum(bits) == (1 << 256) - 1   # disjoint cover
+        for b in bits:                                                      # eight CU slots in every XCD
+            assert [sum((b >> (8 * k + x)) & 1 for k in range(32)) for x in range(8)] == [8] * 8
+    shared = cu_masks(4, "block", share=2)
+    assert all(bin(sum(w << (32 * i) for i, w in enumerate(m))).count("1") == 128 for m in shared)

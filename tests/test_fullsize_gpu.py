@@ -136,3 +136,24 @@ def test_config2_every_lane_of_a_calibrated_group(synth_weights):
             _oracle_every_pair(ref, pair, img2_2, out, range(n))
     finally:
         group.close()
+
+
+def test_config2_headline_protocol_every_pair_of_every_kept_lane():
+    """bench.py's own set-up, not a stand-in for it (tools/lane_parity.py, in a process of its own like the bench): lane 0 + the
+    throughput-mode plan the default `--lanes` resolves to (five requested -> `_l4`), LaneGroup(5).calibrate() with its defaults under
+    the package's hardware-queue request, then EVERY pair of EVERY lane the calibration kept against the CPU oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "lane_parity.py"), "--lanes", "5"], cwd=root, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    m = rec["mapping"]
+    assert rec["lanes_kept"] == m["lanes"] and 1 <= rec["lanes_kept"] <= 5
+    assert m["verified_pairs_per_s"] > 0 and m["attempts"] >= 1 and "reproduced" in m           # the winner was measured again where it was left
+    assert rec["hw_queues"]["env"] is not None and rec["hw_queues"]["runtime_was_up"] is False  # the queue request was made in time
+    assert rec["outputs_finite"] and rec["second_round_bit_equal"]
+    assert rec["pairs_checked"] == 32 * rec["lanes_kept"]
+    assert rec["worst_rel_l1"] < 1e-3, rec["worst_at"]

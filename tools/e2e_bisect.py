@@ -4,6 +4,7 @@ pageable numpy after each piece of set-up bench.py does before it."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import demon_amd.lanes  # noqa: E402,F401   (GPU_MAX_HW_QUEUES before the first HIP call)
 if os.environ.get("E2E_TORCH", "1") == "1":      # bench.py initialises torch's HIP context before the first DemonContext
     import demon_amd  # noqa: F401  (sets GPU_MAX_HW_QUEUES before the runtime starts)
     import torch

@@ -5,6 +5,7 @@
   C  Pipeline.run_buffers (B + asynchronous H2D / D2H on page-locked buffers)"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import demon_amd.lanes  # noqa: E402,F401   (GPU_MAX_HW_QUEUES before the first HIP call)
 import numpy as np
 from demon_amd import DemonContext, weights as W
 from demon_amd.pipeline import Pipeline

@@ -4,6 +4,7 @@ then charges a launch 1 / (5 L) of the time 5 launches x L streams take), with t
 usage: python tools/throughput_profile.py [--lanes 3] [--batch 32] [--version 1]"""
 import argparse, os, re, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import demon_amd.lanes  # noqa: E402,F401   (GPU_MAX_HW_QUEUES before the first HIP call)
 import numpy as np
 from demon_amd import DemonContext, weights as W
 

@@ -5,6 +5,7 @@ usage: python tools/tune.py --height 192 --width 256 --batch 32 [--rounds 3] [--
 import argparse, collections, json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import demon_amd.lanes  # noqa: E402,F401   (GPU_MAX_HW_QUEUES before the first HIP call)
 from demon_amd import DemonContext, weights as W  # noqa: E402
 
 ap = argparse.ArgumentParser()
