@@ -52,39 +52,83 @@ def make_inputs(n, seed, height=192, width=256):
     return pair, img2_2
 
 
-def _cpu_bound_leg():
-    """child process of cpu_baseline (OpenMP reads its binding variables once, at start-up): batch-8 full pipeline on the pool and
-    binding the environment names; prints {"batch8_s": median of 2 timed runs after a warm-up}"""
+def _cpu_pool_leg():
+    """child process of cpu_baseline: the full pipeline on the thread pool (and OpenMP binding) the environment names -- one warm-up
+    (never judged: oneDNN creates its primitives per pool size) and two timed runs at batch 1, then the same at batch 8.  Prints a
+    JSON line after EVERY stage, so that a pool the parent has to stop (time bound) still reports what it finished."""
     import torch
     from demon_amd import weights as W
     from oracle import net_ref
+    t_start = time.perf_counter()
     ref = net_ref.DemonRef(W.synthetic_weights(seed=1))
     pair, img2_2 = make_inputs(8, seed=100)
     torch.set_num_threads(int(os.environ["DEMON_CPU_LEG_THREADS"]))
-    ref.full(pair[:1], img2_2[:1], 3)
-    ref.full(pair, img2_2, 3)
-    ts = []
-    for _ in range(2):
+    rec = {"threads": torch.get_num_threads(), "setup_s": round(time.perf_counter() - t_start, 2)}
+
+    def run(b):
         t0 = time.perf_counter()
-        ref.full(pair, img2_2, 3)
-        ts.append(time.perf_counter() - t0)
-    print(json.dumps({"batch8_s": float(np.median(ts))}))
+        ref.full(pair[:b], img2_2[:b], 3)
+        return time.perf_counter() - t0
+
+    rec["batch1_warmup_s"] = round(run(1), 4)
+    print(json.dumps(rec), flush=True)
+    rec["batch1_s"] = [round(run(1), 4), round(run(1), 4)]
+    rec["batch1_pairs_per_s"] = 1.0 / min(rec["batch1_s"])
+    print(json.dumps(rec), flush=True)
+    run(8)
+    rec["batch8_s"] = [round(run(8), 4), round(run(8), 4)]
+    rec["batch8_pairs_per_s"] = 8.0 / min(rec["batch8_s"])
+    print(json.dumps(rec), flush=True)
 
 
-def cpu_baseline(weights, budget_s=30.0):
+def cpu_baseline(weights, budget_s=20.0, pool_timeout_s=25.0):
     """The CPU oracle (PyTorch-CPU restatement of the TF-CPU path, "port") on this box's host cores, after the protocol of
     SURVEY.md section 8(d): batch 1, batch 8 and the metric's own batch 32, warm-ups + timed full-pipeline runs, MEDIAN pairs/s.
-    Thread pool: EVERY pool of {32, 64, 128, nproc} is measured warm -- one warm-up (oneDNN creates its primitives per pool size)
-    and two timed runs at batch 1, then the same at batch 8 -- and every pool's numbers are in the record (`thread_sweep`); no pool
-    is judged on a cold run.  The one bound: a pool whose WARM batch-1 time is more than 3x the best warm one so far skips its batch-8
-    leg (on this 256-thread host an oversubscribed pool takes minutes per batch; it is listed with its batch-1 numbers).  One more
-    leg runs the best pool in a child process with OMP_PROC_BIND=close OMP_PLACES=cores (binding is read at OpenMP start-up).
-    value = the best pairs/s any leg measured; the final legs (batch 1 / 8 / 32 medians) run on the best pool, bounded to about
-    `budget_s` seconds."""
+    Thread pool: EVERY pool of {32, 64, 128, nproc} is measured WARM in a process of its own (one warm-up run that is never judged --
+    oneDNN creates its primitives per pool size -- then two timed runs at batch 1, then the same at batch 8), every pool's numbers are
+    in the record (`thread_sweep`), and one more leg runs the best pool with OMP_PROC_BIND=close OMP_PLACES=cores (OpenMP reads its
+    binding at start-up: hence the child processes).  The one bound is wall time: a pool gets `pool_timeout_s` seconds; one that has
+    not finished by then (on this 256-thread host an oversubscribed pool takes tens of seconds per pair) is stopped and listed with
+    the stages it did finish.  The final legs (batch 1 / 8 / 32 medians, bounded to about `budget_s` seconds) run in this process on
+    the best pool; value = the best pairs/s any leg measured."""
     import subprocess
     import torch
     from oracle import net_ref
     nproc = os.cpu_count() or 1
+
+    def child(threads, bind):
+        env = dict(os.environ, DEMON_CPU_LEG_THREADS=str(threads), OMP_NUM_THREADS=str(threads))
+        if bind:
+            env.update(OMP_PROC_BIND="close", OMP_PLACES="cores")
+        t0 = time.perf_counter()
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-pool-leg"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        try:
+            out, _ = p.communicate(timeout=pool_timeout_s)
+            stopped = False
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+            stopped = True
+        rec = {}
+        for line in (out or "").splitlines():
+            if line.startswith("{"):
+                try:
+                    rec = json.loads(line)
+                except ValueError:
+                    pass
+        rec["wall_s"] = round(time.perf_counter() - t0, 1)
+        if stopped:
+            rec["stopped"] = "not finished within %.0f s: stages missing here were not reached" % pool_timeout_s
+        if bind:
+            rec["binding"] = "OMP_PROC_BIND=close OMP_PLACES=cores"
+        return rec
+
+    sweep = {}
+    for c in sorted({min(c, nproc) for c in (32, 64, 128, nproc)}):
+        sweep[str(c)] = child(c, False)
+    rate = lambda e: max(e.get("batch8_pairs_per_s", 0.0), e.get("batch1_pairs_per_s", 0.0))   # noqa: E731
+    cores = int(max(sweep, key=lambda k: rate(sweep[k])))
+    bound = child(cores, True)
     ref = net_ref.DemonRef(weights)
     pair, img2_2 = make_inputs(32, seed=100)
 
@@ -93,30 +137,6 @@ def cpu_baseline(weights, budget_s=30.0):
         ref.full(pair[:b], img2_2[:b], 3)
         return time.perf_counter() - t0
 
-    sweep, best_b1 = {}, None
-    for c in sorted({min(c, nproc) for c in (32, 64, 128, nproc)}):
-        torch.set_num_threads(c)
-        run(1)                                        # warm-up: pages in / creates the primitives of this pool size (never judged)
-        b1 = [run(1), run(1)]
-        e = {"batch1_s": [round(t, 4) for t in b1], "batch1_pairs_per_s": 1.0 / min(b1)}
-        if best_b1 is None or min(b1) <= 3.0 * best_b1:
-            run(8)
-            b8 = [run(8), run(8)]
-            e.update(batch8_s=[round(t, 4) for t in b8], batch8_pairs_per_s=8.0 / min(b8))
-        else:
-            e["batch8_skipped"] = "warm batch-1 time %.3f s > 3 x the best pool's %.3f s" % (min(b1), best_b1)
-        best_b1 = min(b1) if best_b1 is None else min(best_b1, min(b1))
-        sweep[str(c)] = e
-    cores = int(max(sweep, key=lambda k: sweep[k].get("batch8_pairs_per_s", 0.0)))
-    # the best pool once more with its threads bound to cores, in a child process
-    bound = None
-    try:
-        env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_NUM_THREADS=str(cores), DEMON_CPU_LEG_THREADS=str(cores))
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-bound-leg"], env=env, capture_output=True, text=True, timeout=120)
-        t8 = json.loads(r.stdout.strip().splitlines()[-1])["batch8_s"]
-        bound = {"threads": cores, "binding": "OMP_PROC_BIND=close OMP_PLACES=cores", "batch8_s": round(t8, 4), "batch8_pairs_per_s": 8.0 / t8}
-    except Exception as e:      # (a baseline leg must never cost the run its JSON line)
-        bound = {"threads": cores, "binding": "OMP_PROC_BIND=close OMP_PLACES=cores", "error": repr(e)[:160]}
     torch.set_num_threads(cores)
     run(1)
     spent = time.perf_counter()
@@ -133,17 +153,18 @@ def cpu_baseline(weights, budget_s=30.0):
     best = max(legs, key=lambda b: legs[b]["pairs_per_s"])
     value, what = legs[best]["pairs_per_s"], "batch %d, %d unbound threads" % (best, cores)
     for k, e in sweep.items():
-        if e.get("batch8_pairs_per_s", 0.0) > value:
-            value, what = e["batch8_pairs_per_s"], "batch 8, %s unbound threads (sweep leg)" % k
-    if bound.get("batch8_pairs_per_s", 0.0) > value:
-        value, what = bound["batch8_pairs_per_s"], "batch 8, %d threads bound to cores" % cores
+        if rate(e) > value:
+            value, what = rate(e), "%s unbound threads (sweep leg)" % k
+    if rate(bound) > value:
+        value, what = rate(bound), "%d threads bound to cores" % cores
     return {"value": value, "unit": "pairs/s", "cores": cores, "nproc": nproc, "kind": "port",
             "batch1_pairs_per_s": legs[1]["pairs_per_s"], "batch8_pairs_per_s": legs[8]["pairs_per_s"], "batch32_pairs_per_s": legs[32]["pairs_per_s"],
-            "thread_sweep": sweep,        # every pool: warm batch-1 and batch-8 times (two timed runs each after a warm-up)
+            "thread_sweep": sweep,        # every pool: warm batch-1 and batch-8 times (two timed runs each after a warm-up), or how far it got in its time bound
             "bound_leg": bound,
             "sample": "full pipeline (boot + 3 iter + refine) @256x192, PyTorch-CPU fp32 oracle; pools 32 / 64 / 128 / %d threads each measured warm at "
-                      "batch 1 and batch 8, the best pool again with OMP_PROC_BIND=close, then medians of %d / %d / %d runs at batch 1 / 8 / 32 on %d "
-                      "threads of %d logical CPUs; value = %s" % (nproc, legs[1]["runs"], legs[8]["runs"], legs[32]["runs"], cores, nproc, what)}
+                      "batch 1 and batch 8 in a process of its own (%.0f s bound per pool), the best pool again with OMP_PROC_BIND=close, then medians of "
+                      "%d / %d / %d runs at batch 1 / 8 / 32 on %d threads of %d logical CPUs; value = %s"
+                      % (nproc, pool_timeout_s, legs[1]["runs"], legs[8]["runs"], legs[32]["runs"], cores, nproc, what)}
 
 
 from demon_amd.kernel_names import rocprof_kernel_name  # noqa: E402
@@ -609,7 +630,7 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--cpu-bound-leg" in sys.argv:
-        _cpu_bound_leg()
+    if "--cpu-pool-leg" in sys.argv:
+        _cpu_pool_leg()
     else:
         main()

@@ -13,11 +13,14 @@ namespace demon {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
-constexpr int SM_CH = 8, SM_TH = 8, SM_TW = 128, SM_STRIDE = SM_TW + 8;  // 136 floats (cols 3..132 used): rows stay 16-byte aligned
+constexpr int SM_CH = 8, SM_TH = 8;
 
-template <int CO>
+// PX: pixels per thread along x (4: tiles of 8 x 128 pixels; 2 (round 6): tiles of 8 x 64 -- the 48 x 64 heads of the blocks are 64 wide, so
+// half of a 128-wide tile's threads computed pixels that do not exist: 26 us per launch for 11 MB)
+template <int CO, int PX>
 __global__ __launch_bounds__(256) void conv_small_kernel(SmallConvArgs a)
 {
+    constexpr int SM_TW = 32 * PX, SM_STRIDE = SM_TW + 8;  // 136 / 72 floats (cols 3 .. TW + 4 used): rows stay 16-byte aligned
     __shared__ __attribute__((aligned(16))) float tile[SM_CH][SM_TH + 2][SM_STRIDE];
     __shared__ __attribute__((aligned(16))) float wl[64 * 9 * CO];  // weights [ci][tap][co]: uniform (broadcast) LDS reads
     for (int e = threadIdx.x; e < a.Cin * 9 * CO; e += 256) {
@@ -30,9 +33,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallConvArgs a)
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int hw = a.H * a.W;
     const float *__restrict__ inp = a.in + (long)n * a.in_n_stride;
-    float acc[4][CO];
+    float acc[PX][CO];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < PX; ++p)
 #pragma unroll
         for (int co = 0; co < CO; ++co) acc[p][co] = 0.0f;
 
@@ -45,11 +48,12 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallConvArgs a)
         {
             const bool vec = (a.W & 3) == 0 && (hw & 3) == 0 && (a.in_n_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
             if (vec) {
-                // 16 bytes per lane: 32 lanes cover the 128 interior columns of one (channel, row), 8 of them per pass
-                const int sub = threadIdx.x >> 5, col = (threadIdx.x & 31) * 4;
+                // 16 bytes per lane: 32 (16) lanes cover the interior columns of one (channel, row), 8 (16) of them per pass
+                constexpr int LPR = SM_TW / 4, RPP = 256 / LPR;   // lanes per row, rows per pass
+                const int sub = threadIdx.x / LPR, col = (threadIdx.x % LPR) * 4;
                 const int gx = x0 + col;
                 const bool xin = gx < a.W;  // W % 4 == 0: a group of four columns is inside or outside as a whole
-                for (int rr = 0; rr < nc * (SM_TH + 2); rr += 8) {
+                for (int rr = 0; rr < nc * (SM_TH + 2); rr += RPP) {
                     const int q = rr + sub;
                     if (q < nc * (SM_TH + 2)) {
                         const int c = q / (SM_TH + 2), row = q - c * (SM_TH + 2);
@@ -60,10 +64,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallConvArgs a)
                     }
                 }
             } else {
-            const int half = threadIdx.x >> 7, col = threadIdx.x & 127;
+            constexpr int RPP = 256 / SM_TW;   // rows per pass
+            const int half = threadIdx.x / SM_TW, col = threadIdx.x % SM_TW;
             const int gx = x0 + col;
             const bool xin = gx < a.W;
-            for (int rr = 0; rr < nc * (SM_TH + 2); rr += 2) {
+            for (int rr = 0; rr < nc * (SM_TH + 2); rr += RPP) {
                 const int q = rr + half;  // (channel, row) pair index
                 if (q < nc * (SM_TH + 2)) {
                     const int c = q / (SM_TH + 2), row = q - c * (SM_TH + 2);  // division by the constant 10
@@ -87,12 +92,18 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallConvArgs a)
         for (int c = 0; c < nc; ++c) {
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                // values x-1 .. x+4 of row ty+dy: LDS columns 4*tx+3 .. 4*tx+8
-                const float *r = &tile[c][ty + dy][4 * tx];
-                const float vm = r[3];
-                const floatx4 v4 = *reinterpret_cast<const floatx4 *>(r + 4);
-                const float vp = r[8];
-                const float v[6] = {vm, v4[0], v4[1], v4[2], v4[3], vp};
+                // values x-1 .. x+PX of row ty+dy: LDS columns PX*tx+3 .. PX*tx+4+PX
+                const float *r = &tile[c][ty + dy][PX * tx];
+                float v[PX + 2];
+                v[0] = r[3];
+                if constexpr (PX == 4) {
+                    const floatx4 v4 = *reinterpret_cast<const floatx4 *>(r + 4);
+                    v[1] = v4[0]; v[2] = v4[1]; v[3] = v4[2]; v[4] = v4[3];
+                } else {
+                    const floatx2 v2 = *reinterpret_cast<const floatx2 *>(r + 4);
+                    v[1] = v2[0]; v[2] = v2[1];
+                }
+                v[PX + 1] = r[4 + PX];
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const float *w = &wl[((c0 + c) * 9 + dy * 3 + dx) * CO];  // wave uniform address: LDS broadcast
@@ -100,32 +111,33 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallConvArgs a)
                     for (int co = 0; co < CO; ++co) {
                         const float wv = w[co];
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) acc[p][co] = fmaf(v[p + dx], wv, acc[p][co]);
+                        for (int p = 0; p < PX; ++p) acc[p][co] = fmaf(v[p + dx], wv, acc[p][co]);
                     }
                 }
             }
         }
     }
-    const int x = x0 + 4 * tx, y = y0 + ty;
+    const int x = x0 + PX * tx, y = y0 + ty;
     if (y >= a.H || x >= a.W) return;
     const float sc = a.scale ? a.scale[n] : 1.0f;
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
         if (co >= a.Cout) break;
         const float b = a.bias[co];
-        float o[4];
+        float o[PX];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < PX; ++p) {
             float v = acc[p][co] + b;
             if (a.act) v = v >= 0.0f ? v : 0.1f * v;
             if (co == 0) v *= sc;
             o[p] = v;
         }
         float *__restrict__ dst = a.out + (long)n * a.out_n_stride + (long)co * hw + y * a.W + x;
-        if (x + 3 < a.W && (a.W & 3) == 0) {
-            *reinterpret_cast<floatx4 *>(dst) = floatx4{o[0], o[1], o[2], o[3]};
+        if (x + PX - 1 < a.W && (a.W & 3) == 0) {
+            if constexpr (PX == 4) *reinterpret_cast<floatx4 *>(dst) = floatx4{o[0], o[1], o[2], o[3]};
+            else *reinterpret_cast<floatx2 *>(dst) = floatx2{o[0], o[1]};
         } else {
-            for (int p = 0; p < 4 && x + p < a.W; ++p) dst[p] = o[p];
+            for (int p = 0; p < PX && x + p < a.W; ++p) dst[p] = o[p];
         }
     }
 }
@@ -134,10 +146,19 @@ bool conv_small_applies(int kh, int kw, int sh, int sw, int Cin, int Cout) { ret
 
 void launch_conv_small(const SmallConvArgs &a, int N, hipStream_t s)
 {
-    dim3 grid((a.W + SM_TW - 1) / SM_TW, (a.H + SM_TH - 1) / SM_TH, N);
-    if (a.Cout <= 1) hipLaunchKernelGGL(conv_small_kernel<1>, grid, dim3(256), 0, s, a);
-    else if (a.Cout <= 2) hipLaunchKernelGGL(conv_small_kernel<2>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(conv_small_kernel<4>, grid, dim3(256), 0, s, a);
+    // maps up to 64 (or 64 + 64 k, k odd ...: whenever the last 128-wide tile would be at most half full) wide: 64-wide tiles
+    const bool narrow = (a.W % 128) != 0 && (a.W % 128) <= 64;
+    const int tw = narrow ? 64 : 128;
+    dim3 grid((a.W + tw - 1) / tw, (a.H + SM_TH - 1) / SM_TH, N);
+    if (narrow) {
+        if (a.Cout <= 1) hipLaunchKernelGGL((conv_small_kernel<1, 2>), grid, dim3(256), 0, s, a);
+        else if (a.Cout <= 2) hipLaunchKernelGGL((conv_small_kernel<2, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_small_kernel<4, 2>), grid, dim3(256), 0, s, a);
+    } else {
+        if (a.Cout <= 1) hipLaunchKernelGGL((conv_small_kernel<1, 4>), grid, dim3(256), 0, s, a);
+        else if (a.Cout <= 2) hipLaunchKernelGGL((conv_small_kernel<2, 4>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_small_kernel<4, 4>), grid, dim3(256), 0, s, a);
+    }
 }
 
 // one workgroup (256 threads) per sample: h2 = lrelu(W2^T x + b2) (128), m = W3^T h2 + b3 (7) -> rotation, translation, scale.

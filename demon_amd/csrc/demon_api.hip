@@ -880,14 +880,17 @@ bool fill_wino4_args(const Layer *L, const ConvArgs &a, int variant, Wino4Args &
     return wino4_plan_geometry(w, L->wino4_kind_of(), variant, L->wino1d_axis());
 }
 
-bool run_wino4(const Layer *L, const ConvArgs &a, int variant, hipStream_t s)
+// ksplit field of the plan entry: 2 = tile-walking workgroups (round 6; falls back to the plain launch where that form does not exist or
+// the tiles fit the chip in one round)
+bool run_wino4(const Layer *L, const ConvArgs &a, int variant, hipStream_t s, int mode = 1)
 {
     if (!wino4_applies(L)) return false;
     refresh_stream_weights(L, s);
     Wino4Args w;
     if (!fill_wino4_args(L, a, variant, w)) return false;
-    if (!launch_wino4(w, L->wino4_kind_of(), variant, L->wino1d_axis(), s)) return false;
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino4<t%d,v%d>", L->wino1d_axis() == 0 ? L->kh : L->kw, variant);
+    const bool walked = mode == 2 && launch_wino4(w, L->wino4_kind_of(), variant, L->wino1d_axis(), s, true);
+    if (!walked && !launch_wino4(w, L->wino4_kind_of(), variant, L->wino1d_axis(), s)) return false;
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, walked ? "wino4<t%d,v%d,walk>" : "wino4<t%d,v%d>", L->wino1d_axis() == 0 ? L->kh : L->kw, variant);
     g_last_kernel = g_kernel_tag;
     return true;
 }
@@ -993,7 +996,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             } else if (kind == 15) {
                 if (run_wino3(L, a, tile, s)) return;
             } else if (kind == 16) {
-                if (run_wino4(L, a, tile, s)) return;
+                if (run_wino4(L, a, tile, s, ks)) return;
             } else if (kind == 13) {
                 if (row_applies(L) && run_row(L, a, s)) return;
             } else if (kind == 12) {
@@ -1037,7 +1040,7 @@ void run_layer(const Layer *L, int n, hipStream_t s, float *ws)
             if (t.kind == 12 && thin_applies(L) && run_thin(L, a, s)) return;
             if (t.kind == 13 && row_applies(L) && run_row(L, a, s)) return;
             if (t.kind == 15 && run_wino3(L, a, t.tile, s)) return;
-            if (t.kind == 16 && run_wino4(L, a, t.tile, s)) return;
+            if (t.kind == 16 && run_wino4(L, a, t.tile, s, t.ksplit)) return;
             if (t.kind == 11 && dense_stream_applies(L) && run_dense_stream(L, a, t.tile, clamp_split(t.ksplit), s)) return;
             if (t.kind == 1) {
                 PatchPlan pp;
@@ -1220,7 +1223,11 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
     if (wino4_applies(L)) {
         for (int v = 0; v < WINO4_VARIANTS; ++v) {
             Wino4Args w;
-            if (fill_wino4_args(L, a, v, w) && wino4_workgroups(w, v) >= 128) cands.push_back({16, v, 1});
+            if (fill_wino4_args(L, a, v, w) && wino4_workgroups(w, v) >= 128) {
+                cands.push_back({16, v, 1});
+                w.gx = (int)wino4_workgroups(w, v); w.gy = 1;
+                if (L->Cin % (4 * wino4_variant_kg(v)) == 0 && wino4_persist_grid(w, L->wino4_kind_of(), v) > 0) cands.push_back({16, v, 2});   // tile-walking form
+            }
         }
     }
     if (wino3_applies(L)) {
@@ -2479,20 +2486,36 @@ int demon_autotune(demon_ctx *c, int n)
     for (auto &g : c->graphs) hipGraphExecDestroy(g.second);  // captured launches embed the old choices
     c->graphs.clear();
     prepare_stream_weights(c);
-    // DEMON_TUNE_ONLY=<substring>: re-tune only the layers whose name contains it (the others keep their installed plan entries)
-    const char *only = getenv("DEMON_TUNE_ONLY");
+    // DEMON_TUNE_ONLY=<substring>[,<substring> ...]: re-tune only the layers whose name contains one of them (the others keep their installed plan entries)
+    const char *only_env = getenv("DEMON_TUNE_ONLY");
+    std::vector<std::string> only_list;
+    for (std::string rest = only_env ? only_env : ""; !rest.empty();) {
+        const size_t e = rest.find(',');
+        if (e) only_list.push_back(rest.substr(0, e));
+        rest = e == std::string::npos ? "" : rest.substr(e + 1);
+    }
+    struct OnlyFilter {
+        const std::vector<std::string> &pats;
+        bool any;
+        bool skips(const std::string &name) const
+        {
+            if (!any) return false;
+            for (const std::string &p : pats) if (name.find(p) != std::string::npos) return false;
+            return true;
+        }
+    } filter{only_list, !only_list.empty()};
     for (auto &L : c->layers) {
-        if (only && *only && L->name.find(only) == std::string::npos) continue;
+        if (filter.skips(L->name)) continue;
         int r = autotune_layer(c, L.get(), n);
         if (r) return fail(c, r, "autotune failed at layer " + L->name);
     }
     for (auto &pr : c->chain_pairs) {
-        if (only && *only && pr.first->name.find(only) == std::string::npos) continue;
+        if (filter.skips(pr.first->name)) continue;
         int r = autotune_chain(c, pr.first, pr.second, n);
         if (r) return fail(c, r, "autotune failed at pair " + pr.first->name);
     }
     for (auto &pr : c->fused_pairs) {
-        if (only && *only && pr.first->name.find(only) == std::string::npos) continue;
+        if (filter.skips(pr.first->name)) continue;
         int r = autotune_fused_pair(c, pr.first, pr.second, n);
         if (r) return fail(c, r, "autotune failed at pair " + pr.first->name);
     }

@@ -375,8 +375,9 @@ struct Wino4Args {
     int sub_shift, pb_shift;             // narrow maps: 2^sub_shift lines side by side in a block, 2^pb_shift positions per line
     int xcd;
     unsigned m_colsx, m_rowsy;
+    int gx, gy;                          // the tile grid: N rows_y cols_x pixel tiles x channel blocks (set by the launcher; a persistent launch has fewer workgroups)
 };
-constexpr int WINO4_VARIANTS = 9;    // workgroup shapes (waves along Cout x waves along positions x lines per wave x K groups per step)
+constexpr int WINO4_VARIANTS = 14;   // workgroup shapes (waves along Cout x waves along positions x lines per wave x K groups per step); 9 ..: three lines per wave
 int wino4_kind(int taps, int stride);   // 0: 3 taps stride 1, 1: 5 taps stride 2, -1: none
 int wino4_nuv(int kind);
 int wino4_variant_bm(int v);
@@ -385,7 +386,10 @@ bool wino4_variant_ok(int kind, int v);
 bool wino4_plan_geometry(Wino4Args &a, int kind, int variant, int axis);
 long wino4_workgroups(const Wino4Args &a, int variant);
 void launch_wino4_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, hipStream_t s);
-bool launch_wino4(const Wino4Args &a, int kind, int variant, int axis, hipStream_t stream);   // false: nothing was launched
+// persist: tile-walking workgroups (a whole number of tiles each, next tile's first loads under the current tile's epilogue); false when the
+// tiles fit the chip in one round anyway (nothing to walk) or nothing was launched
+int wino4_persist_grid(const Wino4Args &a, int kind, int variant);   // workgroups of the persistent launch; 0: not applicable
+bool launch_wino4(const Wino4Args &a, int kind, int variant, int axis, hipStream_t stream, bool persist = false);   // false: nothing was launched
 
 // ---- weight-streaming dense layer at small batch (dense_stream.hip): dense5 (v2), motion_fc1 -----------------------------------------------
 struct DenseArgs {

@@ -75,11 +75,12 @@ def kernel_tag(name):
             return "wino3rows<f4t3x3,v%d>" % shapes4.get(shape, -1)
         shapes3 = {(2, 2, 4, 1): 0, (2, 4, 4, 1): 1, (4, 1, 4, 1): 2, (4, 2, 4, 1): 3, (1, 4, 4, 1): 4, (1, 4, 2, 2): 5, (2, 2, 2, 2): 6, (4, 1, 2, 2): 7}
         return "wino3rows<t3x3,v%d>" % shapes3.get(shape, -1)
-    m = re.search(r"wino4_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)", name)
-    if m:
-        kind, axis, wm, wn, tn, kg = map(int, m.groups())
-        shapes4 = {(4, 1, 4, 1): 0, (4, 1, 2, 2): 1, (2, 2, 4, 1): 2, (2, 2, 2, 2): 3, (4, 2, 2, 2): 4, (4, 2, 4, 1): 5, (4, 1, 1, 4): 6, (2, 2, 1, 4): 7, (2, 2, 2, 1): 8}
-        return "wino4<t%d,v%d>" % (3 if kind == 0 else 5, shapes4.get((wm, wn, tn, kg), -1))
+    m = re.search(r"wino4_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (true|false)", name)
+    if m:   # <KIND, AXIS, WM, WN, TN, KG, MASK, SAMEPAD, PERSIST>; PERSIST: the tile-walking form (round 6)
+        kind, axis, wm, wn, tn, kg = map(int, m.groups()[:6])
+        shapes4 = {(4, 1, 4, 1): 0, (4, 1, 2, 2): 1, (2, 2, 4, 1): 2, (2, 2, 2, 2): 3, (4, 2, 2, 2): 4, (4, 2, 4, 1): 5, (4, 1, 1, 4): 6, (2, 2, 1, 4): 7, (2, 2, 2, 1): 8,
+                   (4, 2, 3, 2): 9, (2, 2, 3, 2): 10, (4, 1, 3, 2): 11, (2, 2, 3, 1): 12, (4, 2, 3, 1): 13}
+        return "wino4<t%d,v%d%s>" % (3 if kind == 0 else 5, shapes4.get((wm, wn, tn, kg), -1), ",walk" if m.group(9) == "true" else "")
     m = re.search(r"conv_row_kernel<(\d+), ", name)
     if m:
         return "conv_row<32x128,t%d>" % (3 + 2 * int(m.group(1)))

@@ -380,7 +380,8 @@ def test_minimal_filtering_3x3_stride2_rows(gpu_ctx, layer):
 WINO4_LAYERS = [(64, 64, 3, 1, 1, 1, 48, 64), (64, 64, 1, 3, 1, 1, 48, 64), (128, 128, 3, 1, 1, 1, 24, 32), (128, 128, 1, 3, 1, 1, 24, 32),
                 (64, 128, 5, 1, 2, 1, 48, 64), (128, 128, 1, 5, 1, 2, 24, 64), (128, 256, 5, 1, 2, 1, 24, 32), (256, 256, 1, 5, 1, 2, 12, 32),
                 (18, 40, 3, 1, 1, 1, 13, 70), (30, 24, 1, 5, 1, 2, 6, 256), (22, 36, 5, 1, 2, 1, 35, 66), (20, 16, 1, 3, 1, 1, 7, 64), (256, 256, 3, 1, 1, 1, 12, 16),
-                (256, 256, 1, 3, 1, 1, 12, 16), (24, 48, 1, 5, 1, 2, 9, 32)]
+                (256, 256, 1, 3, 1, 1, 12, 16), (24, 48, 1, 5, 1, 2, 9, 32),
+                (128, 128, 3, 1, 1, 1, 24, 32), (64, 64, 3, 1, 1, 1, 20, 64), (36, 64, 5, 1, 2, 1, 46, 32)]
 
 
 @pytest.mark.parametrize("layer", WINO4_LAYERS)
@@ -396,18 +397,76 @@ def test_minimal_filtering_four_outputs_per_window(gpu_ctx, layer):
     w = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
     b = rng.standard_normal((cout,)).astype(np.float32)
     want = _ref("conv", x, w, b, (sh, sw))
-    ran = 0
+    ran = walked = 0
     try:
-        for v in range(9):
-            os.environ["DEMON_FORCE_PLAN"] = "16,%d,1" % v
-            got = gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
-            tag = gpu_ctx.last_kernel()
-            if not tag.startswith("wino4<"):
-                continue   # shape not built for this filter (accumulator budget), Cout not a multiple of its channel block, too much waste
-            ran += 1
-            err = rel_l1(got, want)
-            assert err < 1e-5, "variant %d (%s): rel L1 %.3e" % (v, tag, err)
-            np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True))
+        for v in range(14):     # 9 .. 13: the three-lines-per-wave shapes of round 6 (staging units that do not divide the threads)
+            plain = None
+            for mode in (1, 2):   # 2: tile-walking workgroups (round 6; falls back to the plain launch where that form does not exist / one round suffices)
+                os.environ["DEMON_FORCE_PLAN"] = "16,%d,%d" % (v, mode)
+                got = gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
+                tag = gpu_ctx.last_kernel()
+                if not tag.startswith("wino4<"):
+                    break   # shape not built for this filter (accumulator budget), Cout not a multiple of its channel block, too much waste
+                ran += 1
+                err = rel_l1(got, want)
+                assert err < 1e-5, "variant %d (%s): rel L1 %.3e" % (v, tag, err)
+                np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True))
+                if mode == 1:
+                    plain = got
+                else:
+                    walked += ",walk" in tag
+                    np.testing.assert_array_equal(got, plain, err_msg="the tile-walking form computes the same bits (%s)" % tag)
         assert ran >= 1, layer
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+@pytest.mark.parametrize("shape", [(24, 4, 48, 64), (24, 4, 21, 48), (16, 1, 40, 192), (16, 1, 9, 200), (24, 3, 17, 130), (10, 2, 12, 36), (24, 4, 48, 256)])
+def test_small_heads_narrow_and_wide_tiles(gpu_ctx, shape):
+    """conv_small.hip (plan kind 3): the Cout <= 4 heads.  Round 6 gave it 64-wide tiles for maps whose last 128-wide tile would be at most
+    half full (the 48 x 64 heads of every block); both tile widths, widths that are not multiples of 4 (scalar staging path), every
+    Cout instantiation -- against PyTorch, deterministic."""
+    cin, cout, H, W = shape
+    rng = np.random.default_rng(61)
+    x = rng.standard_normal((3, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, cin, cout)) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("conv", x, w, b, (1, 1))
+    try:
+        os.environ["DEMON_FORCE_PLAN"] = "3,0,0"
+        got = gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True)
+        assert gpu_ctx.last_kernel().startswith("conv_small"), gpu_ctx.last_kernel()
+        assert rel_l1(got, want) < 1e-5
+        np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True))
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+@pytest.mark.parametrize("layer", [(64, 64, 3, 1, 48, 64), (64, 64, 1, 3, 48, 64), (128, 128, 3, 1, 24, 32), (128, 128, 1, 3, 24, 32), (256, 256, 3, 1, 12, 16)])
+def test_tile_walking_workgroups_equal_the_plain_launch(gpu_ctx, layer):
+    """conv_wino4.hip, plan field ksplit = 2 (round 6): fewer workgroups than tiles, each walking a whole number of tiles with the next
+    tile's first loads issued under the current tile's epilogue.  At a batch where the tiles exceed one round of the chip the walking
+    form must really run (kernel tag ",walk") and give the plain launch's bits, against PyTorch <= 1e-5."""
+    cin, cout, kh, kw, H, W = layer
+    rng = np.random.default_rng(62)
+    n = 26
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("conv", x, w, b, (1, 1))
+    walked = 0
+    try:
+        for v in range(14):
+            os.environ["DEMON_FORCE_PLAN"] = "16,%d,1" % v
+            plain = gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True)
+            if not gpu_ctx.last_kernel().startswith("wino4<"):
+                continue
+            assert rel_l1(plain, want) < 1e-5, v
+            os.environ["DEMON_FORCE_PLAN"] = "16,%d,2" % v
+            got = gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True)
+            tag = gpu_ctx.last_kernel()
+            np.testing.assert_array_equal(got, plain, err_msg=tag)
+            walked += ",walk" in tag
+        assert walked >= 2, "no shape ran its tile-walking form at batch %d" % n
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
