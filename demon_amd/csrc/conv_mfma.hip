@@ -22,6 +22,9 @@
 // operand reuse (global -> LDS traffic) against the number of workgroups for the small feature maps.
 #include <type_traits>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "internal.h"
 
 namespace demon {
@@ -435,6 +438,7 @@ void launch_conv_mfma(const ConvArgs &a_in, ConvPlan plan, int nclasses, hipStre
     if (plan.ksplit > 1) launch_splitk_reduce(a, nclasses, stream);
 }
 
+thread_local int g_active_cus = 0;
 thread_local hipEvent_t g_reduce_mark = nullptr;
 thread_local bool g_reduce_marked = false;
 
@@ -442,6 +446,15 @@ void launch_splitk_reduce(const ConvArgs &a, int nclasses, hipStream_t stream)
 {
     const long P = (long)a.N * a.Hp * a.Wp;
     if (g_reduce_mark && hipEventRecord(g_reduce_mark, stream) == hipSuccess) g_reduce_marked = true;
+    // diagnostic hook (tools/ablate_lanes.py, row "split-K reduces"): DEMON_SKIP_REDUCE=1 leaves every split-K reduce launch out -- WRONG
+    // results, used only to read off what the reduce launches cost with several passes in flight
+    static const bool skip = [] {
+        const char *e = getenv("DEMON_SKIP_REDUCE");
+        const bool on = e && *e && atoi(e);
+        if (on) fprintf(stderr, "libdemon_hip: DEMON_SKIP_REDUCE is set -- split-K reduce launches are LEFT OUT, all results are WRONG (diagnostic for tools/ablate_lanes.py only)\n");
+        return on;
+    }();
+    if (skip) return;
     if (nclasses == 1 && a.osx == 1 && a.osy == 1 && (a.Wp & 3) == 0 && (a.Wo & 3) == 0 && (a.out_plane & 3) == 0 && (a.out_n_stride & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
         dim3 rgrid((unsigned)((P / 4 + 255) / 256), (unsigned)a.Cout, 1);

@@ -1137,8 +1137,10 @@ float time_replay(demon_ctx *c, const std::function<void()> &body, bool &failed)
 }
 
 // Measures every applicable (kernel, tile, split-K) variant of one layer at batch n and remembers the fastest.
+int mask_cus(const demon_ctx *c);
 int autotune_layer(demon_ctx *c, Layer *L, int n)
 {
+    g_active_cus = mask_cus(c);
     struct Cand { int kind, tile, ksplit; };
     std::vector<Cand> cands;
     ConvArgs a;
@@ -1821,8 +1823,16 @@ bool pair_step_skipped(const demon_ctx *c, const Step &st, int n)
     return st.pair == 1 ? !fused : fused;
 }
 
+int mask_cus(const demon_ctx *c)
+{
+    int k = 0;
+    for (uint32_t w : c->cu_mask) k += __builtin_popcount(w);
+    return k;
+}
+
 void run_steps(demon_ctx *c, const std::vector<Step> &steps, int n, hipStream_t s, int mode, size_t &ev)
 {
+    g_active_cus = mask_cus(c);
     bool branches = c->opt_side_branches && c->side_stream && s == c->stream;
     bool side_open = false;  // work on the side stream that the main stream has not waited for yet
     for (const Step &st : steps) {

@@ -183,6 +183,9 @@ int conv_tile_bn(int tile);
 void launch_splitk_reduce(const ConvArgs &a, int nclasses, hipStream_t stream);
 // demon_profile_full: when set, launch_splitk_reduce records this event on the stream in front of the reduce kernel (and sets the
 // flag), so that a layer's own kernel and the reduce launch that follows it are timed separately
+// compute units the launches of this thread run on: the CU count of the context's mask (demon_set_cu_mask), 0 = the whole device.  Read by the
+// launchers that size a grid by the chip (tile-walking workgroups); set by the entry points that enqueue a context's work.
+extern thread_local int g_active_cus;
 extern thread_local hipEvent_t g_reduce_mark;
 extern thread_local bool g_reduce_marked;
 

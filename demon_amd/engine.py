@@ -132,13 +132,21 @@ class DemonContext:
         for layer, (kind, tile, ks) in plan.items():
             self._check(self.lib.demon_plan_set(self.h, int(n), layer.encode(), int(kind), int(tile), int(ks)))
 
-    def load_tuned_plan(self, n, directory=None, nearest=True, lanes=1):
+    def set_cu_mask(self, mask_words):
+        """demon_set_cu_mask: the context's streams re-created on a compute-unit mask (list of 32-bit words, demon_amd.lanes.cu_masks;
+        None / []: every CU again).  Nothing may be in flight; cached graphs are dropped."""
+        m = list(mask_words or [])
+        arr = (ctypes.c_uint32 * max(1, len(m)))(*m)
+        self._check(self.lib.demon_set_cu_mask(self.h, arr, len(m)))
+
+    def load_tuned_plan(self, n, directory=None, nearest=True, lanes=1, partitions=1):
         """installs demon_amd/tuned/plan_<H>x<W>_n<n>.json; without a plan for exactly this batch the plan of the NEAREST tuned
         batch size of the same shape (by ratio) is used -- its kernel families and tiles transfer, and kernels clamp a split-K
         that does not fit -- instead of the untuned heuristics.  Returns the batch size of the plan installed (== n for an
         exact hit), or 0 when none exists for this shape.  lanes > 1 (the context is one lane of a group, demon_amd/lanes.py):
         a plan tuned in throughput mode (tools/tune.py --lanes: plan_..._n<N>_l<L>.json) is preferred when one exists for the
-        batch size."""
+        batch size.  partitions > 1 (the lanes of the group run on disjoint CU masks, LaneGroup(partitions=...)): a plan tuned on a
+        1 / partitions share of the compute units (tools/tune.py --cu-partitions: plan_..._n<N>_p<P>.json) is preferred over both."""
         import glob
         import json
         import os
@@ -147,6 +155,12 @@ class DemonContext:
         tag = "" if self.version == 1 else "v2_"
         stem = "plan_%s%dx%d_n" % (tag, self.H, self.W)
         have = {}
+        part = {}
+        if partitions > 1:
+            for path in glob.glob(os.path.join(directory, stem + "*_p%d.json" % int(partitions))):
+                m = re.match(re.escape(stem) + r"(\d+)_p\d+\.json$", os.path.basename(path))
+                if m:
+                    part[int(m.group(1))] = path
         for path in glob.glob(os.path.join(directory, stem + "*.json")):
             m = re.match(re.escape(stem) + r"(\d+)\.json$", os.path.basename(path))
             if m:
@@ -159,6 +173,7 @@ class DemonContext:
                     tuned.setdefault(int(m.group(1)), {})[int(m.group(2))] = path
             for b, by_l in tuned.items():
                 have[b] = by_l[min(by_l, key=lambda l: (abs(l - int(lanes)), l))]
+        have.update(part)
         if not have or (int(n) not in have and not nearest):
             return 0
         src = int(n) if int(n) in have else min(have, key=lambda b: abs(np.log(b / float(n))))

@@ -99,11 +99,16 @@ def cu_masks(lanes, layout="block", share=1, slots=32, xcds=8):
 class LaneGroup:
     _cache = {}     # mapping_key -> {"lanes", "placeholder_streams", "pairs_per_s"}
 
-    def __init__(self, weights=None, lanes=3, batch=32, height=192, width=256, device=0, version=1, first=None, plan_batch=None):
+    def __init__(self, weights=None, lanes=3, batch=32, height=192, width=256, device=0, version=1, first=None, plan_batch=None, partitions=1):
         """first: an existing context that becomes lane 0 (it already holds its weights, e.g. a rank's context after the RCCL
-        broadcast); otherwise lane 0 is created here and takes `weights` (dict tf name -> array)."""
+        broadcast); otherwise lane 0 is created here and takes `weights` (dict tf name -> array).
+        partitions = P > 1 (round 6): the compute units are split into P equal shares of every XCD (cu_masks) and lane j runs on share
+        j % P (demon_set_cu_mask) -- lanes on different shares never compete for a CU; the stream -> hardware-queue mapping is still
+        calibrated (two lanes on one queue serialise whatever their masks), but only over placeholder counts: every lane is kept."""
         if lanes < 1:
             raise ValueError("lanes must be >= 1")
+        if partitions < 1 or (partitions > 1 and (32 % partitions or lanes % partitions)):
+            raise ValueError("partitions must divide 32 CU slots per XCD and the lane count")
         self.batch, self.H, self.W, self.device, self.version = batch, height, width, device, version
         self._owns_first = first is None
         self._plan_batch = plan_batch or batch
@@ -121,6 +126,16 @@ class LaneGroup:
                 c.set_plan(self._plan_batch, plan)
             self.ctxs.append(c)
         self._requested = lanes
+        self.partitions = partitions
+        if partitions > 1:
+            if self._owns_first:
+                first.load_tuned_plan(self._plan_batch, lanes=lanes, partitions=partitions)
+                plan = first.get_plan(self._plan_batch)
+                for c in self.ctxs[1:]:
+                    c.clear_plan(self._plan_batch)
+                    c.set_plan(self._plan_batch, plan)
+            pm = cu_masks(partitions, "block")
+            self.set_cu_masks([pm[j % partitions] for j in range(lanes)])
         self._side_off = lanes > 1
         if self._side_off:
             for c in self.ctxs:
@@ -136,6 +151,8 @@ class LaneGroup:
             if i or self._owns_first:
                 c.close()
             else:
+                if self.partitions > 1:
+                    c.set_cu_mask(None)            # the borrowed context gets the whole chip back
                 self._apply(0, ctxs=[c])           # its placeholder streams go; the borrowed context keeps working
                 c.set_option("side_branches", self._first_side)
         self.ctxs = []
@@ -156,10 +173,8 @@ class LaneGroup:
     def mapping_key(self):
         """what a measured (lanes, placeholder streams) winner depends on, as far as this process can tell: the streams other
         libraries hold (torch.distributed / RCCL under a launcher, torch itself) shift the mapping"""
-        import os
-        import sys
-        return "dev%d_%dx%d_v%d_n%d_l%d_ws%s_torch%d" % (self.device, self.H, self.W, self.version, self.batch, self._requested,
-                                                         os.environ.get("WORLD_SIZE", "1"), int("torch" in sys.modules))
+        return "dev%d_%dx%d_v%d_n%d_l%d_p%d_ws%s_torch%d" % (self.device, self.H, self.W, self.version, self.batch, self._requested, self.partitions,
+                                                             os.environ.get("WORLD_SIZE", "1"), int("torch" in sys.modules))
 
     @classmethod
     def _cache_file(cls):
@@ -230,7 +245,7 @@ class LaneGroup:
             if self._owns_first:
                 self.ctxs[0].load_tuned_plan(self._plan_batch, lanes=1)
             self._side_off = False
-        self.mapping = {"lanes": keep, "placeholder_streams": placeholder_streams, "pairs_per_s": rate, "hw_queues": dict(HW_QUEUES)}
+        self.mapping = {"lanes": keep, "placeholder_streams": placeholder_streams, "pairs_per_s": rate, "hw_queues": dict(HW_QUEUES), "cu_partitions": self.partitions}
 
     def calibrate(self, n, iterations=3, bootstrap_only=False, steps_per_lane=4, candidates=None, pads=(0, 1, 2, 3, 4, 5), reuse=False):
         """demon_lanes_calibrate (inputs must be resident in every lane): the rate of `steps_per_lane * k` steps on the first k lanes
@@ -242,6 +257,8 @@ class LaneGroup:
         is applied and measured once; when its rate is back ({} is returned) the sweep is skipped, else the full calibration runs."""
         from ._lib import LanesResult
         import ctypes
+        if self.partitions > 1 and candidates is None:
+            candidates = [len(self.ctxs)]      # every partition keeps its lanes: only the stream mapping is searched
         ks = [k for k in sorted(set(candidates or range(1, len(self.ctxs) + 1))) if 1 <= k <= len(self.ctxs)]
         if not ks:
             raise ValueError("candidates %r: no lane count in [1, %d]" % (candidates, len(self.ctxs)))

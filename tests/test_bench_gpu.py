@@ -72,9 +72,13 @@ def test_bench_default_line_has_roofline_and_host_to_host_rates():
         assert 0.0 < e["frac"] <= 1.0, (key, e["frac"])                                  # executed multiply-adds: a roofline fraction
         assert e["algorithmic_frac"] >= e["frac"] - 1e-12
         assert abs(e["frac"] - e["algorithmic_frac"] * e["mfma_flops_executed_per_algorithmic"]) < 1e-9
-        if rec["config"]["lanes"] > 1:   # the same kernel(s) with that many passes in flight
+        if rec["config"]["lanes"] > 1:   # the entry's own figures are those of the regime `value` ran in; one launch at a time under stand_alone
             f = e["in_flight"]
-            assert f["lanes"] == rec["config"]["lanes"] and 0.0 < f["frac"] <= 1.0 and f["algorithmic_frac"] >= f["frac"] - 1e-12
+            assert e["regime"].startswith("in flight") and f["lanes"] == rec["config"]["lanes"] and f["frac"] == e["frac"]
+            a = e["stand_alone"]
+            assert 0.0 < a["frac"] <= 1.0 and a["algorithmic_frac"] >= a["frac"] - 1e-12 and a["avg_launch_ms"] > 0
+        else:
+            assert e["regime"].startswith("stand-alone")
     assert 0.0 < rec["pipeline_mfma_executed_frac"] <= rec["pipeline_mfma_frac"] <= 1.0
     assert abs(rec["pipeline_mfma_frac"] - rec["value"] * 30.353e9 / 157.3e12) < 1e-9
     assert 1 <= rec["config"]["lanes"] <= 5 and rec["config"]["steps_in_flight_per_gpu"] == rec["config"]["lanes"]

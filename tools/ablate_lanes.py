@@ -11,7 +11,8 @@ GROUPS = [("none", ""), ("conv1y", "/conv1y"), ("conv1x", "/conv1x"), ("conv2", 
           ("extra inputs", "conv2_extra,assemble_inputs"), ("motion", "motion"), ("flow5 head", "predict_flow5,upsample_flow5"),
           ("rf conv0+assemble", "netRefine/conv0,netRefine/assemble"), ("rf conv1", "netRefine/conv1$"), ("rf conv1_1", "netRefine/conv1_1"),
           ("rf conv2", "netRefine/conv2$"), ("rf conv2_1", "netRefine/conv2_1"), ("rf refine1", "netRefine/refine1"), ("rf refine0", "netRefine/refine0"),
-          ("rf pd0 conv1", "predict_depth0/conv1"), ("rf pd0 conv2", "predict_depth0/conv2")]
+          ("rf pd0 conv1", "predict_depth0/conv1"), ("rf pd0 conv2", "predict_depth0/conv2"),
+          ("split-K reduces", "@reduce")]     # every conv_splitk_reduce / dense_reduce-free launch of the pass left out (DEMON_SKIP_REDUCE)
 ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=4)
 ap.add_argument("--batch", type=int, default=32)
@@ -38,7 +39,9 @@ if args.child is not None:
 base = None
 for name, subs in GROUPS:
     env = dict(os.environ)
-    if subs:
+    if subs == "@reduce":
+        env["DEMON_SKIP_REDUCE"] = "1"
+    elif subs:
         env["DEMON_SKIP_STEPS"] = subs
     r = subprocess.run([sys.executable, __file__, "--child", name, "--lanes", str(args.lanes), "--batch", str(args.batch)], env=env, capture_output=True, text=True)
     try:

@@ -16,6 +16,7 @@ ap.add_argument("--rounds", type=int, default=3, help="majority vote over this m
 ap.add_argument("--outdir", default="gpurun_out")
 ap.add_argument("--version", type=int, default=1, choices=[1, 2], help="1 = original model, 2 = v2 model")
 ap.add_argument("--lanes", type=int, default=1, help="throughput mode: time every candidate as this many concurrent replays (option tune_lanes); the plan is written as ..._l<lanes>.json")
+ap.add_argument("--cu-partitions", type=int, default=1, help="tune on 1 / P of the compute units (the context's streams on the CU mask of partition 0, demon_amd.lanes.cu_masks): the regime of a lane group on disjoint CU partitions; one pass at a time; the plan is written as ..._p<P>.json")
 ap.add_argument("--only", default="", help="re-tune only the layers whose name contains this substring, on top of the shipped plan of the batch size")
 args = ap.parse_args()
 os.makedirs(args.outdir, exist_ok=True)
@@ -29,10 +30,15 @@ for n in args.batch:
     ctx.upload_inputs(pair, img2_2)
     ctx.run_full(n, 3)
     ctx.synchronize()
+    if args.cu_partitions > 1:
+        from demon_amd.lanes import cu_masks
+        ctx.set_cu_mask(cu_masks(args.cu_partitions, "block")[0])
+        ctx.run_full(n, 3)
+        ctx.synchronize()
     if args.lanes > 1:
         ctx.set_option("tune_lanes", args.lanes)
     if args.only:
-        assert ctx.load_tuned_plan(n, nearest=False, lanes=args.lanes) == n, "no shipped plan to start from"
+        assert ctx.load_tuned_plan(n, nearest=False, lanes=args.lanes, partitions=args.cu_partitions) == n, "no shipped plan to start from"
         os.environ["DEMON_TUNE_ONLY"] = args.only
     votes = collections.defaultdict(collections.Counter)
     for _ in range(args.rounds):
@@ -40,8 +46,8 @@ for n in args.batch:
         for layer, p in ctx.get_plan(n).items():
             votes[layer][tuple(p)] += 1
     plan = {layer: list(c.most_common(1)[0][0]) for layer, c in votes.items()}
-    path = os.path.join(args.outdir, "plan_%s%dx%d_n%d%s.json" % ("" if args.version == 1 else "v2_", args.height, args.width, n, "_l%d" % args.lanes if args.lanes > 1 else ""))
+    path = os.path.join(args.outdir, "plan_%s%dx%d_n%d%s.json" % ("" if args.version == 1 else "v2_", args.height, args.width, n, ("_p%d" % args.cu_partitions) if args.cu_partitions > 1 else ("_l%d" % args.lanes if args.lanes > 1 else "")))
     with open(path, "w") as f:
-        json.dump({"gpu": "MI355X (gfx950)", "model_version": args.version, "height": args.height, "width": args.width, "batch": n, "tune_lanes": args.lanes, "plan": plan}, f, indent=0, sort_keys=True)
+        json.dump({"gpu": "MI355X (gfx950)", "model_version": args.version, "height": args.height, "width": args.width, "batch": n, "tune_lanes": args.lanes, "cu_partitions": args.cu_partitions, "plan": plan}, f, indent=0, sort_keys=True)
     print(path, len(plan), "layers")
     ctx.close()
