@@ -176,20 +176,26 @@ __global__ __launch_bounds__(ROW_NT, 2) void conv_row_kernel(RowArgs a)
         const int y = ty * ROW_R + r, x = tx * ROW_TX + 2 * tile;
         const bool tv = y < a.Ho && x < a.Wo;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb) {
+            // the output transform on the four channels of an accumulator register group at once (round 6): packed fp32 instructions, two channels each
+            floatx4 m4[NUV], p0, p1;
+#pragma unroll
+            for (int e = 0; e < NUV; ++e) m4[e] = acc[e][cb];
+            K::output(m4, p0, p1);
+            const floatx4 b4 = *reinterpret_cast<const floatx4 *>(a.bias + cb * 16 + 4 * lk);   // (padded to Mpad = 32)
+            p0 += b4; p1 += b4;
+            if (a.act) {
+                const floatx4 l0 = 0.1f * p0, l1 = 0.1f * p1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { p0[q] = fmaxf(p0[q], l0[q]); p1[q] = fmaxf(p1[q], l1[q]); }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int co = cb * 16 + 4 * lk + q;
-                float m[NUV], o0, o1;
-#pragma unroll
-                for (int e = 0; e < NUV; ++e) m[e] = acc[e][cb][q];
-                K::output(m, o0, o1);
-                const float b = a.bias[co];   // (padded to Mpad)
-                float v0 = o0 + b, v1 = o1 + b;
-                if (a.act) { v0 = fmaxf(v0, 0.1f * v0); v1 = fmaxf(v1, 0.1f * v1); }
                 const int off = (tv && co < a.Cout) ? 4 * (co * (int)a.out_plane + y * a.Wo + x) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, floatx2{v0, v1}), orsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, floatx2{p0[q], p1[q]}), orsrc, off, 0, 0);
             }
+        }
         __syncthreads();   // every wave is done reading the patch
     }
 }

@@ -661,16 +661,23 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
             }
             continue;
         }
+        // the output transform on the four channels of an accumulator register group at once (round 6): on floatx4 the compiler emits packed fp32
+        // instructions (two channels each) -- half the vector instructions of the per-channel form
+        floatx4 m4[NUV], p0, p1;
+#pragma unroll
+        for (int e = 0; e < NUV; ++e) m4[e] = acc[tb][e];
+        K::output(m4, p0, p1);
+        const floatx4 b4 = *reinterpret_cast<const floatx4 *>(a.bias + m0 + wm * 16 + 4 * lk);   // (bias is padded to Mpad, a multiple of 16)
+        p0 += b4; p1 += b4;
+        if (a.act) {
+            const floatx4 l0 = 0.1f * p0, l1 = 0.1f * p1;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) { p0[e4] = fmaxf(p0[e4], l0[e4]); p1[e4] = fmaxf(p1[e4], l1[e4]); }
+        }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
             const int col = wm * 16 + 4 * lk + e4;   // channel inside the workgroup's block
-            float m[NUV], o0, o1;
-#pragma unroll
-            for (int e = 0; e < NUV; ++e) m[e] = acc[tb][e][e4];
-            K::output(m, o0, o1);
-            const float b = a.bias[m0 + col];   // (bias is padded to Mpad)
-            float v0 = o0 + b, v1 = o1 + b;
-            if (a.act) { v0 = fmaxf(v0, 0.1f * v0); v1 = fmaxf(v1, 0.1f * v1); }
+            const float v0 = p0[e4], v1 = p1[e4];
             const int off = (tv && m0 + col < a.Cout) ? toff + e4 * plane4 : OOB;
             if (AXIS == 1 && (a.Wo & 1) == 0) {
                 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -40,7 +40,7 @@ __device__ __forceinline__ int w3div(int n, unsigned magic) { return magic ? (in
 struct Rows23 {   // F(2,3) along x: the 3-tap stride-1 kind of wino1d_tables.h with the interface of Wino43
     static constexpr int NUV = Wino1D<0>::NUV, WIN = Wino1D<0>::WIN, OUT = 2;
     static __device__ __forceinline__ void input(const float (&d)[WIN], float (&t)[NUV]) { Wino1D<0>::input(d, t); }
-    static __device__ __forceinline__ void output(const float (&m)[NUV], float (&o)[OUT]) { Wino1D<0>::output(m, o[0], o[1]); }
+    template <class T> static __device__ __forceinline__ void output(const T (&m)[NUV], T (&o)[OUT]) { Wino1D<0>::output(m, o[0], o[1]); }
 };
 
 // WM x WN waves: WM 16-channel blocks x WN blocks of 16 tile columns; TN output rows per wave; KG K groups (of 4 channels) per barrier;
@@ -262,26 +262,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
         const int y = r0 + tb;
         const bool tv = y < a.Ho && x0 < a.Wo;
         const int toff = tv ? 4 * (y * a.Wo + x0) + (wm * 16 + 4 * lk) * plane4 : OOB;
+        // the output transform on the four channels of an accumulator register group at once (round 6): packed fp32 instructions, two channels each
+        floatx4 m4[NUV], o4[OUT];
+#pragma unroll
+        for (int e = 0; e < NUV; ++e) m4[e] = acc[tb][e];
+        K::output(m4, o4);
+        const floatx4 b4 = *reinterpret_cast<const floatx4 *>(a.bias + m0 + wm * 16 + 4 * lk);   // (bias is padded to Mpad, a multiple of 16)
+#pragma unroll
+        for (int j = 0; j < OUT; ++j) {
+            o4[j] += b4;
+            if (a.act) {
+                const floatx4 l4 = 0.1f * o4[j];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) o4[j][e4] = fmaxf(o4[j][e4], l4[e4]);
+            }
+        }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
             const int col = wm * 16 + 4 * lk + e4;
-            float m[NUV], o[OUT];
-#pragma unroll
-            for (int e = 0; e < NUV; ++e) m[e] = acc[tb][e][e4];
-            K::output(m, o);
-            const float b = a.bias[m0 + col];   // (bias is padded to Mpad)
-#pragma unroll
-            for (int j = 0; j < OUT; ++j) {
-                o[j] += b;
-                if (a.act) o[j] = fmaxf(o[j], 0.1f * o[j]);
-            }
             const int off = (tv && m0 + col < a.Cout) ? toff + e4 * plane4 : OOB;
             if constexpr (OUT == 4) {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, floatx4{o[0], o[1], o[2], o[3]}), orsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, floatx4{o4[0][e4], o4[1][e4], o4[2][e4], o4[3][e4]}), orsrc, off, 0, 0);
             } else {
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{o[0], o[1]}), orsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f32x2{o4[0][e4], o4[1][e4]}), orsrc, off, 0, 0);
             }
         }
     }

@@ -122,7 +122,9 @@ def render4(name, taps, stride, comment):
            "        return G[e][t];", "    }",
            "    static __device__ __forceinline__ void input(const float (&d)[WIN], float (&t)[NUV]) {", emit_input(BT, win, name), "    }"]
     names = ["m[%d]" % e for e in range(nuv)]
-    out.append("    static __device__ __forceinline__ void output(const float (&m)[NUV], float (&o)[OUT]) {")
+    out.append("    // (T = float, or a vector of channels: a lane's accumulator registers ARE four consecutive channels, and on float4 the compiler emits")
+    out.append("    // packed fp32 instructions -- v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, two channels each)")
+    out.append("    template <class T> static __device__ __forceinline__ void output(const T (&m)[NUV], T (&o)[OUT]) {")
     for k in range(4):
         out.append("        o[%d] = %s;" % (k, linear(AT[k], names)))
     out += ["    }", "};", ""]
@@ -235,7 +237,7 @@ def render():
         out.append("    }")
         out.append("    // output transform: o[k] = sum_e AT[k][e] m[e]")
         names = ["m[%d]" % e for e in range(nuv)]
-        out.append("    static __device__ __forceinline__ void output(const float (&m)[NUV], float &o0, float &o1) {")
+        out.append("    template <class T> static __device__ __forceinline__ void output(const T (&m)[NUV], T &o0, T &o1) {")
         out.append("        o0 = %s;" % linear(AT[0], names))
         out.append("        o1 = %s;" % linear(AT[1], names))
         out.append("    }")
