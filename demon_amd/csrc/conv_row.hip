@@ -184,10 +184,10 @@ __global__ __launch_bounds__(ROW_NT, 2) void conv_row_kernel(RowArgs a)
             K::output(m4, p0, p1);
             const floatx4 b4 = *reinterpret_cast<const floatx4 *>(a.bias + cb * 16 + 4 * lk);   // (padded to Mpad = 32)
             p0 += b4; p1 += b4;
-            if (a.act) {
-                const floatx4 l0 = 0.1f * p0, l1 = 0.1f * p1;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { p0[q] = fmaxf(p0[q], l0[q]); p1[q] = fmaxf(p1[q], l1[q]); }
+            {
+                const float slope = a.act ? 0.1f : 1.0f;   // leaky relu as max(v, slope v), branch-free (slope 1: the identity)
+                p0 = __builtin_elementwise_max(p0, slope * p0);
+                p1 = __builtin_elementwise_max(p1, slope * p1);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

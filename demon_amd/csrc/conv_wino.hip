@@ -43,20 +43,29 @@ constexpr int WINO_PWL = 40, WINO_NT = 256, WINO_CKS = 4;
 // MB: 16-channel blocks per wave (round 4).  The transformed B fragments of a tile block then feed MB MFMAs each, so the 12 VALU
 // instructions and 9 LDS reads of the input transform are spread over twice the matrix work, and half as many workgroups stage the
 // same input patch.
-template <int TN, int EPT, int OCC, int MB>
+// KH = 2 (round 6, variant 6: the 6 x 8 maps of refine4): the reduction is split INSIDE the workgroup.  blockIdx.z is the output row parity py;
+// the four waves are (K half kh, column parity px): a K-step stages 2 x 4 channels -- channels [4 s, 4 s + 4) for the waves kh = 0 and
+// [Cin / 2 + 4 s, ...) for kh = 1 -- and the two halves' outputs are added through LDS in front of the stores.  256 workgroups for a batch
+// of 32 (8 image groups x 16 channel blocks x 2 row parities) with the whole reduction in one launch: no partial sums in HBM, no reduce launch
+// (the split-K form this replaces ran 128 workgroups x 3 .. 4 K slices and a reduce kernel).
+template <int TN, int EPT, int OCC, int MB, int KH>
 __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
 {
     constexpr int NT = WINO_NT, CKS = WINO_CKS, PWL = WINO_PWL;
-    constexpr int ASZ1 = 4 * 4 * CKS * 16;  // floats of one 16-channel weight tile: [class][tap][k][16 channels]
+    constexpr int PCH = KH * CKS;           // channel planes of one image in the staged patch
+    constexpr int ASZ1 = 4 * 4 * CKS * 16;  // floats of one 16-channel weight tile: [class][tap][k][16 channels]  (KH = 2: [kh][px][tap][k][16])
     constexpr int ASZ = MB * ASZ1;          // [mb][class][tap][k][16]
+    static_assert(KH == 1 || MB == 1, "the in-workgroup K split is built for one channel block per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;               // [2][ASZ]
-    const int patch_floats = a.G * CKS * a.PS;
+    const int patch_floats = a.G * PCH * a.PS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int py = wave >> 1, px = wave & 1;   // this wave's sub-pixel class (cls = wave)
+    const int kh = KH == 2 ? wave >> 1 : 0;                                  // K half of this wave
+    const int py = KH == 2 ? (int)blockIdx.z : wave >> 1, px = wave & 1;   // this wave's sub-pixel class (KH = 1: cls = wave)
     const int l15 = lane & 15, lk = lane >> 4;
-    const int zs = blockIdx.z;
+    const int zs = KH == 2 ? 0 : blockIdx.z;
+    const int khalf = KH == 2 ? a.nsteps_total / 2 : 0;                      // K-steps of one half (nsteps_total even: wino_plan_geometry)
     unsigned bx, by;
     xcd_tile(a.xcd, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, bx, by);
     const int m0 = by * (16 * MB);
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     constexpr int OOB = 0x7ffffff0;        // >= num_records of the buffer resources (rsrc_bytes, internal.h): reads as 0
     // ---- patch loader: element e = tid + i*NT of the [G*CKS][PH][PW] patch, decoded once
     const int plane_elems = a.PH * a.PW;
-    const int nelem = a.G * CKS * plane_elems;
+    const int nelem = a.G * PCH * plane_elems;
     const int dummy_off = 2 * ASZ + 2 * patch_floats + tid;  // floats from smem: this thread's dummy slot (branch-free staging)
     int goff[EPT], lds_p[2][EPT];
     unsigned lastbits = 0;                 // elements whose channel exists in the LAST K-step (Cin not a multiple of 4)
@@ -88,11 +97,12 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
         lds_p[0][i] = lds_p[1][i] = dummy_off;
         if (e < nelem) {
             const int pl = wdiv(e, a.m_plane), pos = e - pl * plane_elems;
-            const int g = pl / CKS, c = pl - g * CKS;
+            const int g = pl / PCH, cc = pl - g * PCH;
+            const int c = cc % CKS, ch = (cc / CKS) * khalf * CKS + c;   // channel inside the K-step / relative to the step's first channel (KH = 2: the second half starts Cin / 2 further)
             const int pr = wdiv(pos, a.m_pw), pc = pos - pr * a.PW;
             const int gy = y_org + pr, gx = x_org + pc;
             const bool ok = ((unsigned)gy < (unsigned)a.H) & ((unsigned)gx < (unsigned)a.W) & (n0 + g < a.N);
-            if (ok) goff[i] = 4 * (g * (int)a.in_n_stride + c * a.H * a.W + gy * a.W + gx);
+            if (ok) goff[i] = 4 * (g * (int)a.in_n_stride + ch * a.H * a.W + gy * a.W + gx);
             lds_p[0][i] = 2 * ASZ + pl * a.PS + pr * PWL + pc;
             lds_p[1][i] = lds_p[0][i] + patch_floats;
             lastbits |= ((last_c0 + c < a.Cin) ? 1u : 0u) << i;
@@ -102,8 +112,10 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     // ---- weight loader: one 16-byte chunk per thread: (class, tap, k, 4 channels) <-> packed row tap*Cin + c0 + k of that class
     int aoff;
     {
-        const int cls = tid >> 6, tap = (tid >> 4) & 3, k = (tid >> 2) & 3, c4 = tid & 3;
-        aoff = 4 * (int)((long)cls * a.cls_w_stride + (long)(tap * a.Cin + k) * a.Mpad + m0 + c4 * 4);
+        const int slot = tid >> 6, tap = (tid >> 4) & 3, k = (tid >> 2) & 3, c4 = tid & 3;
+        const int cls = KH == 2 ? 2 * py + (slot & 1) : slot;          // (KH = 2: slot = (K half, column parity) like the waves)
+        const int k0 = KH == 2 ? (slot >> 1) * khalf * CKS : 0;
+        aoff = 4 * (int)((long)cls * a.cls_w_stride + (long)(tap * a.Cin + k0 + k) * a.Mpad + m0 + c4 * 4);
     }
 
     // ---- fragment addressing: lane = (tile l15 of block tb, channel lk); float index of d[0][0] of the tile in either patch buffer
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
         if (q >= ntile) q = 0;   // padding lanes read a valid address; masked at the store
         const int g = wdiv(q, a.m_tytx), rem = q - g * (a.TY * a.TX);
         const int r = wdiv(rem, a.m_tx), c = rem - r * a.TX;
-        rb[0][tb] = 2 * ASZ + (g * CKS + lk) * a.PS + (2 * r + py) * PWL + 2 * c + px;
+        rb[0][tb] = 2 * ASZ + (g * PCH + kh * CKS + lk) * a.PS + (2 * r + py) * PWL + 2 * c + px;
         rb[1][tb] = rb[0][tb] + patch_floats;
     }
     ra[0] = wave * (4 * CKS * 16) + lane;
@@ -168,9 +180,9 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     //   block TN-1       : its MFMAs | LDS reads of the taps and of block 0 of step s+1
     // so no MFMA waits for an LDS read issued just before it, and nothing but the barrier itself stops the matrix pipe.
     // Buffer safety: the buffer written during step s held step s-1, whose last reads were issued before the barrier of step s-1.
-    const int per_slice = (a.nsteps_total + a.ksplit - 1) / a.ksplit;
+    const int per_slice = KH == 2 ? khalf : (a.nsteps_total + a.ksplit - 1) / a.ksplit;
     const int s_begin = zs * per_slice;
-    const int nsteps = min(a.nsteps_total, s_begin + per_slice) - s_begin;
+    const int nsteps = KH == 2 ? khalf : min(a.nsteps_total, s_begin + per_slice) - s_begin;
     auto phys = [&](int x) { return s_begin + min(x, nsteps - 1); };  // a run-ahead past the end of the slice re-reads its last step
     if (nsteps > 0) {
         load_tiles(pregA, aregA, phys(0));
@@ -267,6 +279,30 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     // output row as 16 bytes, 16 lanes = 256 contiguous bytes (4-byte stores of every second pixel made the big maps store bound).
     const bool wide = a.ksplit == 1 && (a.W & 1) == 0;
     float *X = smem;   // [wave][tb][e][ib][64 lanes]
+    if constexpr (KH == 2) {
+        // the K halves meet here: the kh = 1 waves leave their nine accumulators per tile block in LDS (behind the exchange area; the tile
+        // buffers are free), the kh = 0 waves of the same column parity add them and go on alone (the kh = 1 waves only keep the barriers company)
+        float *Hs = smem + 4 * TN * 4 * 2 * 64;   // [px][tb][q][e][64 lanes]
+        __syncthreads();   // every wave is done reading the tile buffers
+        if (kh == 1) {
+#pragma unroll
+            for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+                for (int q = 0; q < 9; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Hs[(((px * TN + tb) * 9 + q) * 4 + e) * 64 + lane] = acc[0][tb][q][e];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+                for (int q = 0; q < 9; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[0][tb][q][e] += Hs[(((px * TN + tb) * 9 + q) * 4 + e) * 64 + lane];
+        }
+    }
+    const bool mine = KH == 1 || kh == 0;   // this wave transforms, exchanges and stores
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
     const int mc = m0 + 16 * mb;   // first output channel of this block
@@ -282,6 +318,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
         const int y0 = (ty * a.TY + r) * 2, x0 = (tx * a.TX + c) * 2;   // class-grid (= input-grid) position of O[0][0]
         const bool tv = qv && n < a.N && y0 < a.H && x0 < a.W;
         if (wide) {
+            if (!mine) continue;
             float keep[4][2];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -302,7 +339,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
             for (int e = 0; e < 4; ++e) { acc[mb][tb][0][e] = keep[e][0]; acc[mb][tb][1][e] = keep[e][1]; }
             continue;
         }
-        if (!tv) continue;
+        if (!tv || !mine) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int co = mc + 4 * lk + e;
@@ -313,7 +350,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
                 for (int ib = 0; ib < 2; ++ib)
                     o[ia][ib] = (acc[mb][tb][ia * 3 + ib][e] + acc[mb][tb][ia * 3 + ib + 1][e]) + (acc[mb][tb][(ia + 1) * 3 + ib][e] + acc[mb][tb][(ia + 1) * 3 + ib + 1][e]);
             if (a.ksplit > 1) {   // partial sums in output space, layout [cls][slice][Mpad][P] (conv_splitk_reduce finishes)
-                float *__restrict__ ws = a.ws + (((long)wave * a.ksplit + zs) * a.Mpad + co) * P + ((long)n * a.H + y0) * a.W + x0;
+                float *__restrict__ ws = a.ws + (((long)(2 * py + px) * a.ksplit + zs) * a.Mpad + co) * P + ((long)n * a.H + y0) * a.W + x0;
 #pragma unroll
                 for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
@@ -335,6 +372,7 @@ __global__ __launch_bounds__(WINO_NT, OCC) void wino_deconv_kernel(WinoArgs a)
     }
     if (!wide) continue;
     __syncthreads();
+    if (!mine) continue;
     // stores through a buffer resource on this workgroup's corner of the output: uniform 64-bit base, one 32-bit offset per lane;
     // padding lanes, rows past the image and channels past Cout carry an out-of-range offset (dropped by the hardware)
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + (long)n0 * a.out_n_stride + (long)mc * plane, 0, rsrc_bytes(view_floats_left(a.N, n0, a.out_n_stride, a.Cout, mc, plane, (long)a.Ho * a.Wo)), 0x00020000);
@@ -669,10 +707,10 @@ __global__ __launch_bounds__(64 * WM * WN, (Wino1D<KIND>::NUV * TN * 4 <= (KG ==
         K::output(m4, p0, p1);
         const floatx4 b4 = *reinterpret_cast<const floatx4 *>(a.bias + m0 + wm * 16 + 4 * lk);   // (bias is padded to Mpad, a multiple of 16)
         p0 += b4; p1 += b4;
-        if (a.act) {
-            const floatx4 l0 = 0.1f * p0, l1 = 0.1f * p1;
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) { p0[e4] = fmaxf(p0[e4], l0[e4]); p1[e4] = fmaxf(p1[e4], l1[e4]); }
+        {
+            const float slope = a.act ? 0.1f : 1.0f;   // leaky relu as max(v, slope v), branch-free (slope 1: the identity)
+            p0 = __builtin_elementwise_max(p0, slope * p0);
+            p1 = __builtin_elementwise_max(p1, slope * p1);
         }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
@@ -716,13 +754,15 @@ __global__ __launch_bounds__(256) void wino1d_repack_kernel(float *__restrict__ 
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 // variants 0..3: one 16-channel block per wave, 32 / 64 / 48 / 16 tiles per workgroup; 4, 5: two blocks per wave (32 channels), 16 / 32 tiles
-int wino_variant_tn(int v) { return v == 0 ? 2 : (v == 1 ? 4 : (v == 2 ? 3 : (v == 5 ? 2 : 1))); }
-int wino_variant_mb(int v) { return v >= 4 ? 2 : 1; }
+// 6 (round 6): 48 tiles, the reduction split in two INSIDE the workgroup, one workgroup per output row parity (wino_deconv_kernel, KH = 2)
+int wino_variant_tn(int v) { return v == 0 ? 2 : (v == 1 ? 4 : (v == 2 ? 3 : (v == 5 ? 2 : (v == 6 ? 3 : 1)))); }
+int wino_variant_mb(int v) { return (v == 4 || v == 5) ? 2 : 1; }
+int wino_variant_kh(int v) { return v == 6 ? 2 : 1; }
 
-size_t wino_lds_bytes(const WinoArgs &a, int tn, int mb)
+size_t wino_lds_bytes(const WinoArgs &a, int tn, int mb, int kh = 1)
 {
-    const size_t kloop = 2ul * mb * 4 * 4 * WINO_CKS * 16 + 2ul * a.G * WINO_CKS * a.PS + WINO_NT;
-    const size_t exchange = 4ul * tn * 4 * 2 * 64;   // epilogue: [wave][tb][e][ib][lane]
+    const size_t kloop = 2ul * mb * 4 * 4 * WINO_CKS * 16 + 2ul * a.G * kh * WINO_CKS * a.PS + WINO_NT;
+    const size_t exchange = 4ul * tn * 4 * 2 * 64 + (kh == 2 ? 2ul * tn * 9 * 4 * 64 : 0ul);   // epilogue: [wave][tb][e][ib][lane] (+ the second K half's accumulators)
     return sizeof(float) * (kloop > exchange ? kloop : exchange);
 }
 
@@ -730,7 +770,10 @@ size_t wino_lds_bytes(const WinoArgs &a, int tn, int mb)
 bool wino_plan_geometry(WinoArgs &a, int variant, int n)
 {
     const int ntile = 16 * wino_variant_tn(variant);
+    const int kh = wino_variant_kh(variant);
     if (a.Mpad % (16 * wino_variant_mb(variant))) return false;
+    // the in-workgroup K split: two equal halves of whole K-steps, full-row stores (even width), no split across workgroups on top
+    if (kh == 2 && ((a.nsteps_total & 1) || (a.Cin & 3) || (a.W & 1))) return false;
     const int ity = (a.H + 1) / 2, itx = (a.W + 1) / 2;   // tiles of one image
     double best = 1e30;
     bool ok = false;
@@ -742,8 +785,8 @@ bool wino_plan_geometry(WinoArgs &a, int variant, int n)
         if (TY == ity && TX == itx) { G = ntile / (TY * TX); if (G < 1) G = 1; if (G > n) G = n; }
         const int tiles_y = (ity + TY - 1) / TY, tiles_x = (itx + TX - 1) / TX, groups = (n + G - 1) / G;
         const int PH = 2 * TY + 2, PW = 2 * TX + 2;
-        const long elems = (long)G * WINO_CKS * PH * PW;
-        if ((elems + WINO_NT - 1) / WINO_NT > 8) continue;
+        const long elems = (long)G * kh * WINO_CKS * PH * PW;
+        if ((elems + WINO_NT - 1) / WINO_NT > (kh == 2 ? 10 : 8)) continue;
         const double waste = (double)groups * tiles_y * tiles_x * ntile / ((double)n * ity * itx);   // >= 1
         const double cost = waste * (1.0 + 0.02 * (16.0 / TX));
         if (cost < best) {
@@ -757,12 +800,12 @@ bool wino_plan_geometry(WinoArgs &a, int variant, int n)
     auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
     a.m_plane = magic(a.PH * a.PW); a.m_pw = magic(a.PW); a.m_tytx = magic(a.TY * a.TX); a.m_tx = magic(a.TX);
     a.m_tilesx = magic(a.tiles_x); a.m_tilesy = magic(a.tiles_y);
-    return wino_lds_bytes(a, wino_variant_tn(variant), wino_variant_mb(variant)) <= 64 * 1024;
+    return wino_lds_bytes(a, wino_variant_tn(variant), wino_variant_mb(variant), kh) <= (kh == 2 ? 160 : 64) * 1024;
 }
 
 long wino_workgroups(const WinoArgs &a, int variant)
 {
-    return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * (a.Mpad / (16 * wino_variant_mb(variant)));
+    return (long)((a.N + a.G - 1) / a.G) * a.tiles_y * a.tiles_x * (a.Mpad / (16 * wino_variant_mb(variant))) * wino_variant_kh(variant);
 }
 
 template <int TN, int OCC, int MB>
@@ -770,16 +813,36 @@ static void launch_wino_ept(const WinoArgs &a, dim3 grid, size_t lds, hipStream_
 {
     const long elems = (long)a.G * WINO_CKS * a.PH * a.PW;
     const int per_thread = (int)((elems + WINO_NT - 1) / WINO_NT);
-    if (per_thread <= 2) hipLaunchKernelGGL((wino_deconv_kernel<TN, 2, OCC, MB>), grid, dim3(WINO_NT), lds, s, a);
-    else if (per_thread <= 4) hipLaunchKernelGGL((wino_deconv_kernel<TN, 4, OCC, MB>), grid, dim3(WINO_NT), lds, s, a);
-    else if (per_thread <= 6) hipLaunchKernelGGL((wino_deconv_kernel<TN, 6, (MB == 2 && TN == 1 ? OCC - 1 : OCC), MB>), grid, dim3(WINO_NT), lds, s, a);   // (two spilled registers at 3 waves per SIMD)
-    else hipLaunchKernelGGL((wino_deconv_kernel<TN, 8, (OCC > 1 && TN != 3 ? OCC - 1 : OCC), MB>), grid, dim3(WINO_NT), lds, s, a);   // 8 staged elements per thread: one wave per SIMD less, no spills
+    if (per_thread <= 2) hipLaunchKernelGGL((wino_deconv_kernel<TN, 2, OCC, MB, 1>), grid, dim3(WINO_NT), lds, s, a);
+    else if (per_thread <= 4) hipLaunchKernelGGL((wino_deconv_kernel<TN, 4, OCC, MB, 1>), grid, dim3(WINO_NT), lds, s, a);
+    else if (per_thread <= 6) hipLaunchKernelGGL((wino_deconv_kernel<TN, 6, (MB == 2 && TN == 1 ? OCC - 1 : OCC), MB, 1>), grid, dim3(WINO_NT), lds, s, a);   // (two spilled registers at 3 waves per SIMD)
+    else hipLaunchKernelGGL((wino_deconv_kernel<TN, 8, (OCC > 1 && TN != 3 ? OCC - 1 : OCC), MB, 1>), grid, dim3(WINO_NT), lds, s, a);   // 8 staged elements per thread: one wave per SIMD less, no spills
+}
+
+// variant 6: the K halves inside the workgroup, grid z = output row parity; one wave per SIMD (256 workgroups of 256 threads for refine4 at batch 32)
+static bool launch_wino_kh2(const WinoArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    const long elems = (long)a.G * 2 * WINO_CKS * a.PH * a.PW;
+    const int per_thread = (int)((elems + WINO_NT - 1) / WINO_NT);
+    static PerDeviceOnce once6, once10;
+    if (per_thread <= 6) {
+        if (lds > 48 * 1024 && !once6.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_deconv_kernel<3, 6, 1, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; })) return false;
+        hipLaunchKernelGGL((wino_deconv_kernel<3, 6, 1, 1, 2>), grid, dim3(WINO_NT), lds, s, a);
+    } else {
+        if (lds > 48 * 1024 && !once10.ensure([] { return hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_deconv_kernel<3, 10, 1, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; })) return false;
+        hipLaunchKernelGGL((wino_deconv_kernel<3, 10, 1, 1, 2>), grid, dim3(WINO_NT), lds, s, a);
+    }
+    return true;
 }
 
 void launch_wino_deconv(const WinoArgs &a, int variant, hipStream_t stream)
 {
     const int groups = (a.N + a.G - 1) / a.G;
     const int tn = wino_variant_tn(variant), mb = wino_variant_mb(variant);
+    if (wino_variant_kh(variant) == 2) {   // (ksplit is 1 here: run_wino clamps it for this variant)
+        launch_wino_kh2(a, dim3((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / 16), 2), wino_lds_bytes(a, tn, mb, 2), stream);
+        return;
+    }
     dim3 grid((unsigned)(groups * a.tiles_y * a.tiles_x), (unsigned)(a.Mpad / (16 * mb)), (unsigned)a.ksplit);
     const size_t lds = wino_lds_bytes(a, tn, mb);
     if (mb == 2) {

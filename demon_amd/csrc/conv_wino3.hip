@@ -268,14 +268,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino3_rows_kernel(Wino3Args a
         for (int e = 0; e < NUV; ++e) m4[e] = acc[tb][e];
         K::output(m4, o4);
         const floatx4 b4 = *reinterpret_cast<const floatx4 *>(a.bias + m0 + wm * 16 + 4 * lk);   // (bias is padded to Mpad, a multiple of 16)
+        const float slope = a.act ? 0.1f : 1.0f;   // leaky relu as max(v, slope v), branch-free (slope 1: the identity)
 #pragma unroll
         for (int j = 0; j < OUT; ++j) {
             o4[j] += b4;
-            if (a.act) {
-                const floatx4 l4 = 0.1f * o4[j];
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) o4[j][e4] = fmaxf(o4[j][e4], l4[e4]);
-            }
+            o4[j] = __builtin_elementwise_max(o4[j], slope * o4[j]);
         }
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {

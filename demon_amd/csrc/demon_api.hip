@@ -783,11 +783,11 @@ bool run_wino(const Layer *L, const ConvArgs &a, int variant, int ksplit, hipStr
     w.act = a.act; w.xcd = a.xcd;
     w.nsteps_total = (L->Cin + 3) / 4;
     if (!wino_plan_geometry(w, variant, a.N)) return false;
-    if (ksplit < 1) ksplit = 1;
+    if (ksplit < 1 || wino_variant_kh(variant) == 2) ksplit = 1;   // (variant 6 splits the reduction inside the workgroup: nothing across workgroups on top)
     if (ksplit > w.nsteps_total) ksplit = w.nsteps_total;
     w.ksplit = ksplit;
     launch_wino_deconv(w, variant, s);
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino_deconv<%dx%d>%s", 16 * wino_variant_mb(variant), 16 * wino_variant_tn(variant), split_suffix(ksplit));
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, "wino_deconv<%dx%d%s>%s", 16 * wino_variant_mb(variant), 16 * wino_variant_tn(variant), wino_variant_kh(variant) == 2 ? ",kh2" : "", split_suffix(ksplit));
     g_last_kernel = g_kernel_tag;
     if (ksplit > 1) {
         ConvArgs r = a;
@@ -1253,10 +1253,11 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
         const int nsteps = (L->Cin + 3) / 4;
         for (int v = 0; v < WINO_VARIANTS; ++v) {
             WinoArgs w;
-            w.N = n; w.H = a.H; w.W = a.W; w.Mpad = L->Mpad;
+            w.N = n; w.H = a.H; w.W = a.W; w.Mpad = L->Mpad; w.Cin = L->Cin; w.nsteps_total = nsteps;
             if (!wino_plan_geometry(w, v, n)) continue;
             const long wgs = wino_workgroups(w, v);
             for (int ks : {1, 2, 3, 4, 6, 8, 12, 16}) {
+                if (ks > 1 && wino_variant_kh(v) == 2) continue;
                 if (ks > 1 && (ks > nsteps / 8 || wgs * ks > 4096 || (long)L->ncls * ks * L->Mpad * P > kSplitKWorkspaceFloats)) continue;
                 if (wgs * ks < 96) continue;
                 cands.push_back({8, v, ks});

@@ -297,7 +297,8 @@ struct WinoArgs {
     int xcd;
     unsigned m_plane, m_pw, m_tytx, m_tx, m_tilesx, m_tilesy;   // magic numbers for the prologue divisions
 };
-constexpr int WINO_VARIANTS = 6;   // tiles per workgroup: 32, 64, 48, 16 (16 output channels); 16, 32 (32 output channels)
+constexpr int WINO_VARIANTS = 7;   // tiles per workgroup: 32, 64, 48, 16 (16 output channels); 16, 32 (32 output channels); 6: 48 tiles with the reduction split in two inside the workgroup
+int wino_variant_kh(int v);
 int wino_variant_tn(int v);
 int wino_variant_mb(int v);
 bool wino_plan_geometry(WinoArgs &a, int variant, int n);

@@ -53,6 +53,9 @@ def kernel_tag(name):
             if p == params:
                 return "conv_frag<%dx%d,v%d>" % (32 * tm * wm, 32 * tn * wn, v)
         return "conv_frag<%dx%d,?>" % (32 * tm * wm, 32 * tn * wn)
+    m = re.search(r"wino_deconv_kernel<(\d+), \d+, \d+, (\d+), 2>", name)
+    if m:   # <TN, EPT, OCC, MB, KH = 2>: the reduction split in two inside the workgroup (round 6, variant 6)
+        return "wino_deconv<%dx%d,kh2>" % (16 * int(m.group(2)), 16 * int(m.group(1)))
     m = re.search(r"wino_deconv_kernel<(\d+), \d+, \d+, (\d+)", name)
     if m:   # <tile blocks, staged elements per thread, waves per SIMD, 16-channel blocks per wave>
         return "wino_deconv<%dx%d>" % (16 * int(m.group(2)), 16 * int(m.group(1)))
@@ -108,7 +111,9 @@ def rocprof_kernel_name(tag):
     if fam == "conv_patch" and len(dims) == 2:
         return "demon::conv_patch_kernel<%s, ...> (%sx%s tile, %s taps)" % (dims[0], dims[0], dims[1], rest.rstrip(">").split(",t")[-1])
     if fam == "wino_deconv" and len(dims) == 2:
-        return "demon::wino_deconv_kernel<%d, ..., %d> (%s channels x %s tiles per workgroup)" % (int(dims[1]) // 16, int(dims[0]) // 16, dims[0], dims[1])
+        kh2 = ",kh2" in rest
+        return "demon::wino_deconv_kernel<%d, ..., %d, %d> (%s channels x %s tiles per workgroup%s)" % (
+            int(dims[1]) // 16, int(dims[0]) // 16, 2 if kh2 else 1, dims[0], dims[1], ", reduction split in two inside the workgroup" if kh2 else "")
     if fam == "wino4":
         return "demon::wino4_kernel<...> (%s)" % rest.rstrip(">")
     if fam == "wino3rows":

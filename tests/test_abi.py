@@ -127,8 +127,9 @@ def test_kernel_names_round_trip():
         "void demon::conv_patch_kernel<64, 2, 2, 1, 1, 4, 4, 2>(demon::PatchArgs)": "conv_patch<64x64,t4>",
         "void demon::conv_mfma_kernel<128, 32, 4, 1, false>(demon::ConvArgs)": "conv_mfma<128x32>",
         "void demon::deconv4_kernel<32, 1, 4, 4>(demon::PatchArgs)": "deconv4<32x128>",
-        "void demon::wino_deconv_kernel<2, 4, 3, 1>(demon::WinoArgs)": "wino_deconv<16x32>",
-        "void demon::wino_deconv_kernel<1, 2, 3, 2>(demon::WinoArgs)": "wino_deconv<32x16>",
+        "void demon::wino_deconv_kernel<2, 4, 3, 1, 1>(demon::WinoArgs)": "wino_deconv<16x32>",
+        "void demon::wino_deconv_kernel<1, 2, 3, 2, 1>(demon::WinoArgs)": "wino_deconv<32x16>",
+        "void demon::wino_deconv_kernel<3, 10, 1, 1, 2>(demon::WinoArgs)": "wino_deconv<16x48,kh2>",
         "void demon::wino1d_kernel<1, 0, 2, 2, 2, 1, false>(demon::Wino1Args)": "wino1d<t5,v0>",
         "void demon::wino1d_kernel<0, 1, 4, 1, 4, 2, false>(demon::Wino1Args)": "wino1d<t3,v5>",
         "void demon::wino1d_kernel<0, 0, 4, 1, 3, 4, false>(demon::Wino1Args)": "wino1d<t3,v8>",
@@ -148,8 +149,10 @@ def test_kernel_names_round_trip():
         "void demon::wino3_rows_kernel<2, 2, 4, 1, false, 0>(demon::Wino3Args)": "wino3rows<t3x3,v0>",
         "void demon::wino3_rows_kernel<4, 1, 3, 1, false, 1>(demon::Wino3Args)": "wino3rows<f4t3x3,v11>",
         "void demon::wino3_rows_kernel<8, 1, 2, 1, false, 2>(demon::Wino3Args)": "wino3rows<s2t3x3,v19>",
-        "void demon::wino4_kernel<1, 0, 4, 2, 2, 2, false, false>(demon::Wino4Args)": "wino4<t5,v4>",
-        "void demon::wino4_kernel<0, 1, 2, 2, 2, 1, false, false>(demon::Wino4Args)": "wino4<t3,v8>",
+        "void demon::wino4_kernel<1, 0, 4, 2, 2, 2, false, false, false>(demon::Wino4Args)": "wino4<t5,v4>",
+        "void demon::wino4_kernel<0, 1, 2, 2, 2, 1, false, false, false>(demon::Wino4Args)": "wino4<t3,v8>",
+        "void demon::wino4_kernel<0, 0, 4, 2, 3, 2, false, false, false>(demon::Wino4Args)": "wino4<t3,v9>",
+        "void demon::wino4_kernel<0, 1, 4, 1, 2, 2, false, false, true>(demon::Wino4Args)": "wino4<t3,v1,walk>",
     }
     for name, tag in more.items():
         assert kernel_tag(name) == tag
