@@ -472,6 +472,7 @@ def test_tile_walking_workgroups_equal_the_plain_launch(gpu_ctx, layer):
             assert rel_l1(got, want) < 1e-5 and rel_l1(got, plain) < 1e-6, tag     # (last-bit differences: another template instance, other multiply-add contractions)
             np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (1, 1), lrelu=True), err_msg=tag)   # deterministic
             walked += ",walk" in tag
-        assert walked >= 2, "no shape ran its tile-walking form at batch %d" % n
+        if H * W >= 24 * 32:   # (the 12 x 16 layer has fewer tiles than the chip has workgroup slots at this batch: nothing to walk, the plain launch runs)
+            assert walked >= 2, "no shape ran its tile-walking form at batch %d" % n
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
