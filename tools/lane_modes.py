@@ -33,6 +33,8 @@ def child(mode, steps, batch):
     kind, _, spec = mode.partition("-")
     if kind == "rr":
         lanes = 4 if spec == "nocal" else 5
+    elif kind == "rrside":      # rrside-<L>: L lanes WITH the side branches of a pass on (two streams per lane), stream mapping calibrated for exactly L lanes
+        lanes = int(spec)
     elif kind == "pmask":       # pmask-<L>-<P>[c][l]: L lanes over P CU partitions (lane j on partition j % P); c: calibrate the stream mapping; l: latency plan
         lanes = int(spec.split("-")[0])
     else:
@@ -61,6 +63,15 @@ def child(mode, steps, batch):
     if mode == "rr":
         g.calibrate(n, 3)
         note["mapping"] = {k: v for k, v in g.mapping.items() if k != "hw_queues"}
+    if kind == "rrside":
+        for c in g.ctxs:
+            c.set_option("side_branches", 1)
+        g.run_resident(n, len(g), 3)
+        g.synchronize()
+        rates = g.calibrate(n, 3, candidates=[lanes], pads=(0, 1, 2, 3, 4, 5, 6, 7))
+        note["mapping"] = {k: v for k, v in g.mapping.items() if k != "hw_queues"}
+        note["cells"] = {k: round(v) for k, v in rates.items() if k.startswith("%d@" % lanes)}
+        note["side_branches"] = [c.get_option("side_branches") for c in g.ctxs]
     if kind == "pmask" and "c" in spec.split("-")[1]:
         rates = g.calibrate(n, 3, candidates=[lanes], pads=(0, 1, 2, 3, 4, 5, 6, 7))
         note["mapping"] = {k: v for k, v in g.mapping.items() if k != "hw_queues"}
