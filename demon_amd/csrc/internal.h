@@ -380,6 +380,7 @@ struct Wino4Args {
     int xcd;
     unsigned m_colsx, m_rowsy;
     int gx, gy;                          // the tile grid: N rows_y cols_x pixel tiles x channel blocks (set by the launcher; a persistent launch has fewer workgroups)
+    unsigned m_gx;                       // magic number of the division by gx (tile-walking launches split a linear tile index with it)
 };
 constexpr int WINO4_VARIANTS = 14;   // workgroup shapes (waves along Cout x waves along positions x lines per wave x K groups per step); 9 ..: three lines per wave
 int wino4_kind(int taps, int stride);   // 0: 3 taps stride 1, 1: 5 taps stride 2, -1: none

@@ -22,7 +22,7 @@ timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-fo
 # the summaries of these passes into profiles/ ON THE BOX (stamped with the hash of the kernel sources + plans), so that the bench records taken
 # next report the rocprofv3 clock and the PMC traffic beside their own numbers; run tools/finish_profiles.py again at home on the merged files
 python tools/finish_profiles.py $tag > $out/finish_on_box.log 2>&1
-timeout 400 python bench.py --layers > $out/bench.json 2> $out/layers_hipevents.txt
+( time timeout 700 python bench.py --layers ) > $out/bench.json 2> $out/layers_hipevents.txt
 for spec in "config1_bootstrap:--workload bootstrap" "batch1:--batch 1" "batch8:--batch 8" "batch64:--batch 64" "config4_hires:--workload hires --layers" "v2:--workload v2 --layers"; do
   name=${spec%%:*}; args=${spec#*:}
   timeout 400 python bench.py $args --no-cpu-baseline > $out/bench_$name.json 2> $out/layers_$name.txt
@@ -38,6 +38,9 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/hires_fetch -
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/hires_write -o p -- $H > $out/hires_write.log 2>&1
 python tools/hires_counters.py $out/hires_fetch $out/hires_write $out/hires_stats profiles/${tag}_hires_counters.json > $out/hires_counters.log 2>&1
 find $out/hires_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} profiles/${tag}_hires_kernel_stats.csv
+# 6b. the headline's own protocol against the CPU oracle (every pair of every kept lane), and the lane-mode table (round 6)
+timeout 400 python tools/lane_parity.py --lanes 5 > profiles/${tag}_lane_parity.json 2> $out/lane_parity.err
+timeout 900 python tools/lane_modes.py --steps 40 --modes rr,pmask-4-4c,pmask-4-2c,group-4,group-3,rrside-4,quarter,rr > profiles/${tag}_lane_modes.txt 2> $out/lane_modes.err
 # 7. the RCCL route as the driver launches a rank, and the whole -m gpu suite with the reasons of its skips
 DEMON_FORCE_DIST=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29577 bench.py --gpus 1 --no-cpu-baseline --no-roofline --no-e2e > $out/forcedist.out 2> $out/forcedist.err
 grep "^{" $out/forcedist.out | tail -1 > profiles/${tag}_forcedist_rccl_1rank.json
