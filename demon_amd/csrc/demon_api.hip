@@ -870,27 +870,29 @@ bool run_wino3(const Layer *L, const ConvArgs &a, int variant, hipStream_t s)
 // k x 1 / 1 x k convs with four outputs per window (conv_wino4.hip), plan kind 16: variant = workgroup shape
 bool wino4_applies(const Layer *L) { return L->d_w4 != nullptr && L->wino4_kind_of() >= 0; }
 
-bool fill_wino4_args(const Layer *L, const ConvArgs &a, int variant, Wino4Args &w)
+bool fill_wino4_args(const Layer *L, const ConvArgs &a, int variant, Wino4Args &w, bool flat = false)
 {
     w.in = a.in; w.out = a.out; w.wu = L->d_w4; w.bias = a.bias;
     w.N = a.N; w.Cin = L->Cin; w.Cin4 = L->Cin4(); w.H = a.H; w.W = a.W; w.Ho = a.Ho; w.Wo = a.Wo; w.in_n_stride = a.in_n_stride;
     w.Cout = L->Cout; w.Mpad = L->Mpad; w.out_n_stride = a.out_n_stride; w.out_plane = a.out_plane;
     w.act = a.act; w.xcd = a.xcd;
     w.pad = L->wino1d_axis() == 0 ? L->ph : L->pw;
-    return wino4_plan_geometry(w, L->wino4_kind_of(), variant, L->wino1d_axis());
+    return wino4_plan_geometry(w, L->wino4_kind_of(), variant, L->wino1d_axis(), flat);
 }
 
 // ksplit field of the plan entry: 2 = tile-walking workgroups (round 6; falls back to the plain launch where that form does not exist or
-// the tiles fit the chip in one round)
+// the tiles fit the chip in one round), 3 = flat line order (round 6: the lines of all images as one sequence, for maps whose lines per image
+// do not fill a workgroup; falls back to the plain launch where that saves no line block)
 bool run_wino4(const Layer *L, const ConvArgs &a, int variant, hipStream_t s, int mode = 1)
 {
     if (!wino4_applies(L)) return false;
     refresh_stream_weights(L, s);
     Wino4Args w;
-    if (!fill_wino4_args(L, a, variant, w)) return false;
+    const bool flat = mode == 3 && fill_wino4_args(L, a, variant, w, true);
+    if (!flat && !fill_wino4_args(L, a, variant, w)) return false;
     const bool walked = mode == 2 && launch_wino4(w, L->wino4_kind_of(), variant, L->wino1d_axis(), s, true);
     if (!walked && !launch_wino4(w, L->wino4_kind_of(), variant, L->wino1d_axis(), s)) return false;
-    snprintf(g_kernel_tag, sizeof g_kernel_tag, walked ? "wino4<t%d,v%d,walk>" : "wino4<t%d,v%d>", L->wino1d_axis() == 0 ? L->kh : L->kw, variant);
+    snprintf(g_kernel_tag, sizeof g_kernel_tag, walked ? "wino4<t%d,v%d,walk>" : (flat ? "wino4<t%d,v%d,flat>" : "wino4<t%d,v%d>"), L->wino1d_axis() == 0 ? L->kh : L->kw, variant);
     g_last_kernel = g_kernel_tag;
     return true;
 }
@@ -1230,6 +1232,7 @@ int autotune_layer(demon_ctx *c, Layer *L, int n)
                 w.gx = (int)wino4_workgroups(w, v); w.gy = 1;
                 if (L->Cin % (4 * wino4_variant_kg(v)) == 0 && wino4_persist_grid(w, L->wino4_kind_of(), v) > 0) cands.push_back({16, v, 2});   // tile-walking form
             }
+            if (fill_wino4_args(L, a, v, w, true) && wino4_workgroups(w, v) >= 96) cands.push_back({16, v, 3});   // flat line order (only where it saves line blocks)
         }
     }
     if (wino3_applies(L)) {

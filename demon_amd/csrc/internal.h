@@ -381,6 +381,12 @@ struct Wino4Args {
     unsigned m_colsx, m_rowsy;
     int gx, gy;                          // the tile grid: N rows_y cols_x pixel tiles x channel blocks (set by the launcher; a persistent launch has fewer workgroups)
     unsigned m_gx;                       // magic number of the division by gx (tile-walking launches split a linear tile index with it)
+    // round 6, plan field ksplit = 3 ("flat"): the lines of ALL images form one sequence (line g -> image g / lines_img, line g % lines_img), so
+    // that maps whose lines per image do not fill a workgroup's TN x 2^sub_shift lines (12 x 16: 12 rows / 3 tile rows against 8 or 16) leave no
+    // empty slots.  rows_y then counts the line blocks of the whole batch and a unit's image enters its load / store offset.
+    int flat, lines_img, nlines;         // lines per image, N lines_img
+    unsigned m_lines;                    // magic number of the division by lines_img
+    int in_img_bytes, out_img_bytes;     // 4 in_n_stride, 4 out_n_stride (the host refuses batches whose last image would not fit a 31-bit offset)
 };
 constexpr int WINO4_VARIANTS = 14;   // workgroup shapes (waves along Cout x waves along positions x lines per wave x K groups per step); 9 ..: three lines per wave
 int wino4_kind(int taps, int stride);   // 0: 3 taps stride 1, 1: 5 taps stride 2, -1: none
@@ -388,7 +394,7 @@ int wino4_nuv(int kind);
 int wino4_variant_bm(int v);
 int wino4_variant_kg(int v);
 bool wino4_variant_ok(int kind, int v);
-bool wino4_plan_geometry(Wino4Args &a, int kind, int variant, int axis);
+bool wino4_plan_geometry(Wino4Args &a, int kind, int variant, int axis, bool flat = false);   // flat: false when it would not save a line block
 long wino4_workgroups(const Wino4Args &a, int variant);
 void launch_wino4_repack(float *wu, const float *wp, int kind, int Cin, int Cin4, int Mpad, hipStream_t s);
 // persist: tile-walking workgroups (a whole number of tiles each, next tile's first loads under the current tile's epilogue); false when the

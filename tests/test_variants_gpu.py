@@ -405,7 +405,7 @@ def test_minimal_filtering_four_outputs_per_window(gpu_ctx, layer):
     try:
         for v in range(14):     # 9 .. 13: the three-lines-per-wave shapes of round 6 (staging units that do not divide the threads)
             plain = None
-            for mode in (1, 2):   # 2: tile-walking workgroups (round 6; falls back to the plain launch where that form does not exist / one round suffices)
+            for mode in (1, 2, 3):   # 2: tile-walking workgroups (round 6; falls back to the plain launch where that form does not exist / one round suffices); 3: flat line order (falls back where it saves no line block)
                 os.environ["DEMON_FORCE_PLAN"] = "16,%d,%d" % (v, mode)
                 got = gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
                 tag = gpu_ctx.last_kernel()
@@ -421,6 +421,46 @@ def test_minimal_filtering_four_outputs_per_window(gpu_ctx, layer):
                     walked += ",walk" in tag
                     assert rel_l1(got, plain) < 1e-6, tag
         assert ran >= 1, layer
+    finally:
+        os.environ.pop("DEMON_FORCE_PLAN", None)
+
+
+# (cin, cout, kh, kw, sh, sw, H, W, batch)
+WINO4_FLAT_LAYERS = [(256, 256, 1, 3, 1, 1, 12, 16, 7), (256, 256, 3, 1, 1, 1, 12, 16, 7), (256, 256, 1, 5, 1, 2, 12, 32, 5), (128, 256, 5, 1, 2, 1, 24, 32, 5),
+                     (512, 512, 1, 3, 1, 1, 6, 8, 9), (512, 512, 1, 5, 1, 2, 6, 16, 9), (64, 48, 3, 1, 1, 1, 6, 8, 11), (40, 24, 1, 3, 1, 1, 5, 8, 6),
+                     (36, 64, 5, 1, 2, 1, 10, 16, 7), (20, 40, 1, 5, 1, 2, 3, 32, 13), (128, 128, 1, 3, 1, 1, 24, 32, 3), (24, 32, 3, 1, 1, 1, 9, 16, 10)]
+
+
+@pytest.mark.parametrize("layer", WINO4_FLAT_LAYERS)
+def test_flat_line_order_equals_the_per_image_tiles(gpu_ctx, layer):
+    """conv_wino4.hip, plan field ksplit = 3 (round 6): the lines of all images of the batch form one sequence, so that maps whose lines per
+    image do not fill a workgroup's lines (12 x 16: 12 rows or 3 tile rows against 8 / 16) leave no empty slots -- a tile then holds lines of
+    several images, every staging unit and every store carries its image in the buffer offset.  Batches that end in a ragged block, odd map
+    sizes, Cin / Cout that do not fill the channel blocks; against PyTorch, against the per-image launch, deterministic."""
+    cin, cout, kh, kw, sh, sw, H, W, n = layer
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((n, cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)).astype(np.float32)
+    b = rng.standard_normal((cout,)).astype(np.float32)
+    want = _ref("conv", x, w, b, (sh, sw))
+    flat = 0
+    try:
+        for v in range(14):
+            os.environ["DEMON_FORCE_PLAN"] = "16,%d,3" % v
+            got = gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
+            tag = gpu_ctx.last_kernel()
+            if ",flat>" not in tag:
+                continue
+            flat += 1
+            err = rel_l1(got, want)
+            assert err < 1e-5, "variant %d (%s): rel L1 %.3e" % (v, tag, err)
+            np.testing.assert_array_equal(got, gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True))
+            os.environ["DEMON_FORCE_PLAN"] = "16,%d,1" % v
+            plain = gpu_ctx.conv2d(x, w, b, (sh, sw), lrelu=True)
+            if gpu_ctx.last_kernel() == "wino4<t%d,v%d>" % (max(kh, kw), v):
+                np.testing.assert_array_equal(got, plain)   # same template instance, same sums per output: bit-identical
+        if (H, W) in ((12, 16), (12, 32), (6, 8), (6, 16)):
+            assert flat >= 1, layer
     finally:
         os.environ.pop("DEMON_FORCE_PLAN", None)
 
