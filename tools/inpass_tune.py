@@ -37,29 +37,29 @@ FAMILY = {0: ("conv_mfma<",), 1: ("conv_patch<", "deconv4<"), 4: ("conv_stream<"
 SKIP_KINDS = (3, 6, 7, 11, 12, 13, 14)   # small-Cout, chained pairs (and their partners), dense stream, first-layer kernels: left alone
 
 
-def candidates():
+def candidates(ks_list=(1, 2, 3, 4, 6, 8)):
     c = []
     for v in range(14):
         for m in (1, 2, 3):
             c.append((16, v, m))
     for v in range(13):
-        for ks in (1, 2, 3, 4, 6, 8):
+        for ks in ks_list:
             c.append((10, v, ks))
     for v in range(22):
-        for ks in (1, 2, 3, 4, 6, 8):
+        for ks in ks_list:
             c.append((5, v, ks))
     for v in range(18):
-        for ks in (1, 2, 4):
+        for ks in ks_list:
             c.append((4, v, ks))
     for v in range(7):
-        for ks in (1, 2, 3, 4, 6, 8):
+        for ks in ks_list:
             c.append((8, v, ks))
     for v in range(20):
         c.append((15, v, 1))
     for t in range(9):
         c.append((1, t, 0))
     for t in range(8):
-        for ks in (1, 2, 4):
+        for ks in ks_list:
             c.append((0, t, ks))
     return c
 
@@ -79,18 +79,22 @@ def tag_matches(cand, tag):
     return True
 
 
-def inputs(n, seed):
+def inputs(n, seed, H=192, W_=256):
     rng = np.random.default_rng(seed)
-    pair = rng.random((n, 6, 192, 256), dtype=np.float32) - np.float32(0.5)
-    return pair, pair[:, 3:6].reshape(n, 3, 48, 4, 64, 4).mean(axis=(3, 5)).astype(np.float32)
+    pair = rng.random((n, 6, H, W_), dtype=np.float32) - np.float32(0.5)
+    return pair, pair[:, 3:6].reshape(n, 3, H // 4, 4, W_ // 4, 4).mean(axis=(3, 5)).astype(np.float32)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--lanes", type=int, default=1)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--version", type=int, default=1, choices=[1, 2])
     ap.add_argument("--only", default="", help="comma-separated substrings of layer names (default: every layer with a plan entry of a tunable kind)")
     ap.add_argument("--kinds", default="", help="comma-separated plan kinds to draw candidates from (default: all)")
+    ap.add_argument("--ks", default="1,2,3,4,6,8", help="split-K values tried on the kernels that have them (small batches: add 12,16,24,32)")
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--margin", type=float, default=0.02, help="a candidate replaces the installed entry only if it is faster by this fraction in the confirmation round")
@@ -98,19 +102,20 @@ def main():
     ap.add_argument("--verify", type=int, default=0)
     args = ap.parse_args()
     n, L = args.batch, args.lanes
-    w = W.synthetic_weights(seed=1)
-    ctx = DemonContext(0, n)
+    H, Wd = args.height, args.width
+    w = W.synthetic_weights(seed=1, height=H, width=Wd, version=args.version)
+    ctx = DemonContext(0, n, H, Wd, version=args.version)
     ctx.set_weights(w)
     assert ctx.load_tuned_plan(n, nearest=False, lanes=L) == n
     plan_file = ctx.plan_file
-    ctx.upload_inputs(*inputs(n, 0))
+    ctx.upload_inputs(*inputs(n, 0, H, Wd))
     others = []
     for i in range(1, L):
-        o = DemonContext(0, n)
+        o = DemonContext(0, n, H, Wd, version=args.version)
         o.copy_weights_from(ctx) if hasattr(o, "copy_weights_from") else o.set_weights(w)
         o.load_tuned_plan(n, nearest=False, lanes=L)
         o.set_option("side_branches", 0)
-        o.upload_inputs(*inputs(n, i))
+        o.upload_inputs(*inputs(n, i, H, Wd))
         others.append(o)
     if L > 1:
         ctx.set_option("side_branches", 0)   # (a lane of a group runs without them, demon_amd/lanes.py)
@@ -121,7 +126,7 @@ def main():
     chained = {k[:-1] for k, (kind, _, _) in base.items() if kind in (6, 7)}
     targets = [k for k in targets if k[:-1] not in chained]
     kinds = {int(k) for k in args.kinds.split(",") if k}
-    cands = [c for c in candidates() if not kinds or c[0] in kinds]
+    cands = [c for c in candidates(tuple(int(k) for k in args.ks.split(","))) if not kinds or c[0] in kinds]
     print("plan %s, %d target layers, %d candidates, lanes %d" % (plan_file, len(targets), len(cands), L), flush=True)
 
     def profile(reps):

@@ -32,12 +32,14 @@ def main():
     args = ap.parse_args()
     base = json.load(open(args.base))
     alts = [json.load(open(p))["plan"] for p in args.alt]
-    n = args.batch
-    g = LaneGroup(W.synthetic_weights(seed=1), args.lanes, n)
+    # shape, batch and model follow the base plan's own header
+    n = args.batch = int(base.get("batch", args.batch))
+    H, Wd, version = int(base.get("height", 192)), int(base.get("width", 256)), int(base.get("model_version", 1))
+    g = LaneGroup(W.synthetic_weights(seed=1, height=H, width=Wd, version=version), args.lanes, n, height=H, width=Wd, version=version)
     rng = np.random.default_rng(0)
     for c in g.ctxs:
-        pair = rng.random((n, 6, 192, 256), dtype=np.float32) - np.float32(0.5)
-        c.upload_inputs(pair, pair[:, 3:6].reshape(n, 3, 48, 4, 64, 4).mean(axis=(3, 5)).astype(np.float32))
+        pair = rng.random((n, 6, H, Wd), dtype=np.float32) - np.float32(0.5)
+        c.upload_inputs(pair, pair[:, 3:6].reshape(n, 3, H // 4, 4, Wd // 4, 4).mean(axis=(3, 5)).astype(np.float32))
 
     def install(plan):
         for c in g.ctxs:
