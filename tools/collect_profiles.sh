@@ -23,7 +23,7 @@ timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-fo
 # next report the rocprofv3 clock and the PMC traffic beside their own numbers; run tools/finish_profiles.py again at home on the merged files
 python tools/finish_profiles.py $tag > $out/finish_on_box.log 2>&1
 ( time timeout 700 python bench.py --layers ) > $out/bench.json 2> $out/layers_hipevents.txt
-for spec in "config1_bootstrap:--workload bootstrap" "batch1:--batch 1" "batch8:--batch 8" "batch64:--batch 64" "config4_hires:--workload hires --layers" "v2:--workload v2 --layers"; do
+for spec in "config1_bootstrap:--workload bootstrap" "batch1:--batch 1 --layers" "batch8:--batch 8 --layers" "batch64:--batch 64" "config4_hires:--workload hires --layers" "v2:--workload v2 --layers"; do
   name=${spec%%:*}; args=${spec#*:}
   timeout 400 python bench.py $args --no-cpu-baseline > $out/bench_$name.json 2> $out/layers_$name.txt
 done

@@ -28,7 +28,7 @@ def main():
         if name.startswith("bench") and name.endswith(".json"):
             with open(os.path.join(dst, "%s_%s" % (tag, name)), "w") as f:
                 f.write(json_line(os.path.join(src, name)))
-    for a, b in (("layers_hipevents.txt", "layers_hipevents.txt"), ("layers_config4_hires.txt", "layers_hires_hipevents.txt"), ("layers_v2.txt", "layers_v2_hipevents.txt"),
+    for a, b in (("layers_hipevents.txt", "layers_hipevents.txt"), ("layers_config4_hires.txt", "layers_hires_hipevents.txt"), ("layers_v2.txt", "layers_v2_hipevents.txt"), ("layers_batch1.txt", "layers_batch1_hipevents.txt"), ("layers_batch8.txt", "layers_batch8_hipevents.txt"),
                  ("throughput_profile.txt", "throughput_profile.txt")):
         if os.path.exists(os.path.join(src, a)):
             shutil.copyfile(os.path.join(src, a), os.path.join(dst, "%s_%s" % (tag, b)))
