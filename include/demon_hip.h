@@ -117,7 +117,9 @@ int demon_autotune(demon_ctx *ctx, int n);
  *           stride 1: tile = workgroup shape 0..7 on F(2,3) tiles, 8..15 on F(4,3) tiles; stride 2 (rows of a multiple of 8 pixels):
  *           tile 16..19, polyphase F(4,2) + F(4,1)),
  *        16 k x 1 / 1 x k conv with four outputs per window (conv_wino4.hip: F(4,3) for 3 taps stride 1, F(4,3) + F(4,2) for 5 taps
- *           stride 2; tile = workgroup shape 0..8);
+ *           stride 2; tile = workgroup shape 0..13; ksplit field = launch form: 1 one workgroup per tile, 2 tile-walking workgroups, 3 flat
+ *           line order -- the lines of all images of the batch as one sequence, for maps whose lines per image do not fill a workgroup;
+ *           a form that does not exist for the shape, or would save nothing, runs as form 1);
  *   tile = tile / variant id of that kernel; ksplit = K slices across workgroups, combined by a conv_splitk_reduce launch.
  *   demon_plan_get returns DEMON_ERR_NOT_FOUND for an untuned layer. */
 int demon_num_layers(const demon_ctx *ctx);
