@@ -8,6 +8,11 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# errors the HIP runtime / RCCL report are printed (both are silent by default); must be in the environment before the runtime starts
+# (pytest.ini has the story of the silent abort this is here for)
+os.environ.setdefault("AMD_LOG_LEVEL", "1")
+os.environ.setdefault("NCCL_DEBUG", "WARN")
+
 # the lane tests run in this process: demon_amd.lanes exports GPU_MAX_HW_QUEUES when it is imported, which must happen before the
 # first HIP call (bench.py imports it at its top for the same reason)
 import demon_amd.lanes  # noqa: E402,F401

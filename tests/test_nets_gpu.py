@@ -520,7 +520,11 @@ def test_lane_group_calibration_keeps_results(synth_weights):
         group.run_resident(n, 3, iterations=2)
         group.synchronize()
         before = [c.download_outputs(n) for c in group.ctxs]
-        rates = group.calibrate(n, iterations=2, steps_per_lane=2, pads=(0, 1, 2))
+        os.environ["DEMON_LANES_FULL_SWEEP"] = "1"     # (round 6: the sweep stops on a plateau unless told otherwise; here every cell is wanted)
+        try:
+            rates = group.calibrate(n, iterations=2, steps_per_lane=2, pads=(0, 1, 2))
+        finally:
+            os.environ.pop("DEMON_LANES_FULL_SWEEP", None)
         assert set(rates) >= {"1@0", "2@0", "3@0", "2@1", "3@2"} and all(v > 0 for v in rates.values())
         assert group.mapping["lanes"] == len(group) and 1 <= len(group) <= 3 and group.mapping["placeholder_streams"] in (0, 1, 2)
         group.run_resident(n, len(group), iterations=2)
