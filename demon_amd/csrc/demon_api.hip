@@ -2237,9 +2237,18 @@ RcclApi &rccl()
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // An RCCL that is already in the process is the one to use (PyTorch brings its own copy, torch/lib/librccl.so: two copies of the library in
+        // one process answer each other's symbols and end in "double free or corruption" at exit -- seen in round 6 when this loader ran BEFORE
+        // `import torch` and had put /opt/rocm's copy into the global scope).  So: first ask for a loaded one (RTLD_NOLOAD), then load one --
+        // RTLD_LOCAL, so that a host that imports PyTorch afterwards still gets PyTorch's copy for PyTorch.
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *name : names) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
             if (api.lib) break;
+        }
+        for (const char *name : names) {
+            if (api.lib) break;
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!api.lib) { api.err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return; }
         api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
